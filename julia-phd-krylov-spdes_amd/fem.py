@@ -1,0 +1,586 @@
+"""Host-side set-up that feeds the Schur-PCG hot path (boundary producer).
+
+In the reference all of this runs once per realization on the host (Julia) and hands
+arrays-of-SparseMatrixCSC plus index maps to the operators. It is NOT the hot path and
+has no device kernels here either; it exists so that tests, `bench.py` and `smoke()` have
+blocks of exactly the reference's shape to feed through the C ABI.
+
+Citations are relative to /root/reference. "EPDD.jl" = Fem/EllipticPdeDomainDecomposition.jl.
+
+Conventions (differences from the reference are layout only):
+  * indices are 0-based here (the reference is 1-based Julia); `-1` means "absent";
+  * the reference's `Dict{Int,Int}` maps are flat integer arrays
+    (`gather_idx[d][l_Γd] = l_Γ` replaces `ind_Γd_Γ2l[d]`, EPDD.jl:186-191);
+  * domains are numbered 0..ndom-1; `node_owner` keeps the reference's coding shifted by
+    nothing for the special values: -1 = on Γ, -2 = Dirichlet, d>=0 = interior of d
+    (reference: -1 / 0 / d>=1, EPDD.jl:43-46);
+  * sparse blocks are scipy CSR. The symmetric blocks (A, A_II, A_ΓΓ) have identical
+    CSR and CSC arrays; `A_IΓ` (n_I x n_Γd) is kept in CSR, i.e. the CSC arrays of its
+    transpose `A_ΓI`.
+
+Deviations from the reference that are not layout (SURVEY.md N2, §2 Mesh.jl row):
+  * mesh = structured triangulation of the unit square (TriangleMesh is unavailable);
+  * partition = element boxes (mpmetis is unavailable);
+  * interior solves in set-up (`assemble_local_schurs`, `get_schur_rhs`,
+    `get_subdomain_solutions`) use a sparse direct factorisation (scipy SuperLU) where
+    the reference uses `IterativeSolvers.cg` to reltol 1e-9 / sqrt(eps).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Union
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+Coeff = Union[np.ndarray, Callable[[np.ndarray, np.ndarray], np.ndarray]]
+
+
+# --------------------------------------------------------------------------------------
+# Mesh and partition (substitutes for Fem/Mesh.jl:21-31 get_mesh and :169-195 mesh_partition)
+# --------------------------------------------------------------------------------------
+@dataclass
+class Mesh:
+    cells: np.ndarray           # (3, nel) int64, 0-based, counter-clockwise
+    points: np.ndarray          # (2, nnode) float64
+    point_marker: np.ndarray    # (nnode,) int64, 1 = Dirichlet boundary node
+    cell_neighbors: np.ndarray  # (3, nel) int64, neighbour across the edge opposite vertex j, -1 = boundary
+    N: int                      # nodes per side
+
+
+def get_mesh(N: int) -> Mesh:
+    """Structured P1 triangulation of the unit square with N x N nodes.
+
+    Stands in for `get_mesh(tentative_nnode)` (Fem/Mesh.jl:21-31), which calls Triangle.
+    Same output fields as the TriMesh the reference consumes (`cell`, `point`,
+    `point_marker`, `cell_neighbor`); every boundary node is Dirichlet as in the
+    reference's `point_marker`.
+    """
+    if N < 3:
+        raise ValueError("need N >= 3")
+    xs = np.linspace(0.0, 1.0, N)
+    X, Y = np.meshgrid(xs, xs, indexing="xy")          # node id = j*N + i, x = xs[i], y = xs[j]
+    points = np.stack([X.ravel(), Y.ravel()]).astype(np.float64)
+    ii, jj = np.meshgrid(np.arange(N), np.arange(N), indexing="xy")
+    marker = ((ii == 0) | (ii == N - 1) | (jj == 0) | (jj == N - 1)).astype(np.int64).ravel()
+
+    nc = N - 1
+    ci, cj = np.meshgrid(np.arange(nc), np.arange(nc), indexing="xy")
+    ci, cj = ci.ravel(), cj.ravel()                    # cell id c = cj*nc + ci
+    n00 = cj * N + ci
+    n10, n01, n11 = n00 + 1, n00 + N, n00 + N + 1
+    nel = 2 * nc * nc
+    cells = np.empty((3, nel), dtype=np.int64)
+    cells[:, 0::2] = np.stack([n00, n10, n11])         # T0 of each cell
+    cells[:, 1::2] = np.stack([n00, n11, n01])         # T1 of each cell
+    c = cj * nc + ci
+    nb = np.full((3, nel), -1, dtype=np.int64)
+    # T0 = (n00, n10, n11): opposite n00 -> right cell's T1; n10 -> own T1; n11 -> lower cell's T1
+    nb[0, 0::2] = np.where(ci + 1 < nc, 2 * (c + 1) + 1, -1)
+    nb[1, 0::2] = 2 * c + 1
+    nb[2, 0::2] = np.where(cj > 0, 2 * (c - nc) + 1, -1)
+    # T1 = (n00, n11, n01): opposite n00 -> upper cell's T0; n11 -> left cell's T0; n01 -> own T0
+    nb[0, 1::2] = np.where(cj + 1 < nc, 2 * (c + nc), -1)
+    nb[1, 1::2] = np.where(ci > 0, 2 * (c - 1), -1)
+    nb[2, 1::2] = 2 * c
+    return Mesh(cells, points, marker, nb, N)
+
+
+def mesh_partition(mesh: Mesh, px: int, py: int):
+    """Element-box partition into px x py subdomains; returns (epart, npart), 0-based.
+
+    Stands in for `mesh_partition(cells, ndom)` (Fem/Mesh.jl:169-195, mpmetis -contig).
+    `npart[node]` is the domain of one element that owns the node, which is all
+    `set_subdomains` needs (it reads npart only for nodes off the interface, EPDD.jl:168-174).
+    """
+    N = mesh.N
+    nc = N - 1
+    nel = mesh.cells.shape[1]
+    c = np.arange(nel) // 2
+    ci, cj = c % nc, c // nc
+    bx = np.minimum(ci * px // nc, px - 1)
+    by = np.minimum(cj * py // nc, py - 1)
+    epart = (by * px + bx).astype(np.int64)
+    npart = np.full(N * N, -1, dtype=np.int64)
+    # last writer wins; any owner is valid for nodes off Γ
+    for k in range(3):
+        npart[mesh.cells[k]] = epart
+    return epart, npart
+
+
+# --------------------------------------------------------------------------------------
+# Dirichlet index maps (Fem/BoundaryConditions.jl:35-57)
+# --------------------------------------------------------------------------------------
+@dataclass
+class DirichletInds:
+    dirichlet_g2l: np.ndarray       # (nnode,) -1 where not Dirichlet
+    not_dirichlet_g2l: np.ndarray   # (nnode,) -1 where Dirichlet
+    dirichlet_l2g: np.ndarray
+    not_dirichlet_l2g: np.ndarray
+
+
+def get_dirichlet_inds(points: np.ndarray, point_marker: np.ndarray) -> DirichletInds:
+    """`get_dirichlet_inds` (Fem/BoundaryConditions.jl:35-57): ascending-node numbering of both sets."""
+    nnode = points.shape[1]
+    is_d = point_marker.ravel() == 1
+    d_l2g = np.flatnonzero(is_d).astype(np.int64)
+    nd_l2g = np.flatnonzero(~is_d).astype(np.int64)
+    d_g2l = np.full(nnode, -1, dtype=np.int64)
+    nd_g2l = np.full(nnode, -1, dtype=np.int64)
+    d_g2l[d_l2g] = np.arange(d_l2g.size)
+    nd_g2l[nd_l2g] = np.arange(nd_l2g.size)
+    return DirichletInds(d_g2l, nd_g2l, d_l2g, nd_l2g)
+
+
+def append_bc(dinds: DirichletInds, u_no_dirichlet, points, uexact):
+    """`append_bc` (Fem/BoundaryConditions.jl:94-115)."""
+    u = np.empty(points.shape[1])
+    g = dinds.dirichlet_l2g
+    u[g] = _eval(uexact, points[0, g], points[1, g])
+    u[dinds.not_dirichlet_l2g] = u_no_dirichlet
+    return u
+
+
+def _eval(fn, x, y):
+    out = fn(x, y)
+    return np.broadcast_to(np.asarray(out, dtype=np.float64), np.shape(x)).astype(np.float64)
+
+
+def _first_unique(a: np.ndarray) -> np.ndarray:
+    """Unique values of `a` in order of first occurrence."""
+    _, first = np.unique(a, return_index=True)
+    return a[np.sort(first)]
+
+
+# --------------------------------------------------------------------------------------
+# set_subdomains (EPDD.jl:86-193)
+# --------------------------------------------------------------------------------------
+@dataclass
+class Subdomains:
+    ndom: int
+    node_owner: np.ndarray              # (nnode,) -1 Γ, -2 Dirichlet, d interior
+    node_Γ: np.ndarray                  # Γ-local -> global node (first-encounter order)
+    node_Γ_cnt: np.ndarray              # (n_Γ,) number of subdomains sharing each Γ node
+    node_Γd: List[np.ndarray]           # per domain: Γd-local -> global node (first-encounter order)
+    node_Id: List[np.ndarray]           # per domain: I-local -> global node (ascending)
+    gather_idx: List[np.ndarray]        # per domain: Γd-local -> Γ-local (flat ind_Γd_Γ2l)
+    ind_Γ_g2l: np.ndarray               # (nnode,) global -> Γ-local or -1
+    ind_I_g2l: np.ndarray               # (nnode,) global -> I-local in its owner domain or -1
+    elemd: List[np.ndarray]             # elements of each domain (ascending)
+
+    @property
+    def n_Γ(self) -> int:
+        return int(self.node_Γ.size)
+
+    @property
+    def n_Γd(self) -> List[int]:
+        return [int(a.size) for a in self.node_Γd]
+
+    @property
+    def n_Id(self) -> List[int]:
+        return [int(a.size) for a in self.node_Id]
+
+
+def set_subdomains(cells, cell_neighbors, epart, npart, dirichlet_g2l) -> Subdomains:
+    """`set_subdomains` (EPDD.jl:86-193).
+
+    Γ = non-Dirichlet nodes shared by two edge-neighbouring elements of different
+    subdomains (:125-152). Γ and every Γ_d are numbered by first encounter in the
+    element loop (`for iel`, `for j in 1:3`, `for node in iel_cell`, :114-156);
+    interiors are numbered by ascending node id within their `npart` owner (:167-181).
+    """
+    nel = cells.shape[1]
+    nnode = int(cells.max()) + 1
+    ndom = int(epart.max()) + 1
+    is_dir = dirichlet_g2l >= 0
+
+    # candidate events in reference loop order: (iel, j) with a neighbour in another domain
+    jel = cell_neighbors                                    # (3, nel)
+    valid = jel >= 0
+    other = np.zeros_like(valid)
+    other[valid] = epart[jel[valid]] != np.broadcast_to(epart, jel.shape)[valid]
+    ev_j, ev_iel = np.nonzero(other)                        # row-major: sorted by j then iel
+    order = np.lexsort((ev_j, ev_iel))                      # sort by iel, then j
+    ev_iel, ev_j = ev_iel[order], ev_j[order]
+    ev_jel = jel[ev_j, ev_iel]
+    # for every event, nodes of iel (in cell order) that also belong to jel and are not Dirichlet
+    icell = cells[:, ev_iel]                                # (3, nev)
+    jcell = cells[:, ev_jel]
+    shared = (icell[:, None, :] == jcell[None, :, :]).any(axis=1)   # (3, nev)
+    shared &= ~is_dir[icell]
+    k_idx, e_idx = np.nonzero(shared)
+    seq = np.lexsort((k_idx, e_idx))                        # event order, then vertex order
+    cand_nodes = icell[k_idx[seq], e_idx[seq]]
+    cand_dom = epart[ev_iel[e_idx[seq]]]
+
+    node_Γ = _first_unique(cand_nodes) if cand_nodes.size else np.empty(0, np.int64)
+    ind_Γ_g2l = np.full(nnode, -1, dtype=np.int64)
+    ind_Γ_g2l[node_Γ] = np.arange(node_Γ.size)
+
+    node_owner = np.full(nnode, -3, dtype=np.int64)
+    node_owner[is_dir] = -2
+    node_owner[node_Γ] = -1
+
+    node_Γd, gather_idx = [], []
+    node_Γ_cnt = np.zeros(node_Γ.size, dtype=np.int64)
+    for d in range(ndom):
+        nd = cand_nodes[cand_dom == d]
+        nd = _first_unique(nd) if nd.size else np.empty(0, np.int64)
+        node_Γd.append(nd.astype(np.int64))
+        g = ind_Γ_g2l[nd]
+        gather_idx.append(g.astype(np.int64))
+        node_Γ_cnt[g] += 1
+
+    free_int = np.flatnonzero(node_owner == -3)
+    node_owner[free_int] = npart[free_int]
+    node_Id, ind_I_g2l = [], np.full(nnode, -1, dtype=np.int64)
+    for d in range(ndom):
+        nid = free_int[npart[free_int] == d]
+        node_Id.append(nid.astype(np.int64))
+        ind_I_g2l[nid] = np.arange(nid.size)
+
+    elemd = [np.flatnonzero(epart == d).astype(np.int64) for d in range(ndom)]
+    return Subdomains(ndom, node_owner, node_Γ.astype(np.int64), node_Γ_cnt, node_Γd, node_Id,
+                      gather_idx, ind_Γ_g2l, ind_I_g2l, elemd)
+
+
+# --------------------------------------------------------------------------------------
+# Element kernels shared by the assemblies
+# --------------------------------------------------------------------------------------
+def _element_terms(cells, points, coeff: Coeff, f, uexact):
+    """Per-element quantities, evaluated in the reference's operation order.
+
+    Δa = (a1+a2+a3)/3 (EPDD.jl:260-269); shoelace terms (:272-277); Area (:280);
+    ΔKij = Δa*(Δyi*Δyj + Δxi*Δxj)/4/Area (:294); Δb_i = (2f_i+f_j+f_k)*Area/12 (:340-349).
+    """
+    x = points[0][cells]            # (3, nel)
+    y = points[1][cells]
+    if callable(coeff):
+        a = _eval(coeff, x, y)
+    else:
+        a = np.asarray(coeff, dtype=np.float64)[cells]
+    Δa = np.zeros(cells.shape[1])
+    for j in range(3):
+        Δa = Δa + a[j]
+    Δa = Δa / 3.0
+    Δx = np.stack([x[2] - x[1], x[0] - x[2], x[1] - x[0]])
+    Δy = np.stack([y[1] - y[2], y[2] - y[0], y[0] - y[1]])
+    Area = (Δx[2] * Δy[1] - Δx[1] * Δy[2]) / 2.0
+    K = np.empty((3, 3, cells.shape[1]))
+    for i in range(3):
+        for j in range(3):
+            K[i, j] = Δa * (Δy[i] * Δy[j] + Δx[i] * Δx[j]) / 4 / Area
+    fv = _eval(f, x, y)
+    b = np.empty((3, cells.shape[1]))
+    for i in range(3):
+        j, k = (i + 1) % 3, (i + 2) % 3
+        b[i] = (2 * fv[i] + fv[j] + fv[k]) * Area / 12
+    ue = _eval(uexact, x, y)
+    return K, b, ue
+
+
+def _coo_to_csr(I, J, V, shape, seq=None) -> sp.csr_matrix:
+    """`sparse(I,J,V,m,n)`: duplicates are summed in order of occurrence (deterministic)."""
+    if I.size == 0:
+        return sp.csr_matrix(shape, dtype=np.float64)
+    if seq is None:
+        seq = np.arange(I.size)
+    order = np.lexsort((seq, J, I))
+    I, J, V = I[order], J[order], V[order]
+    new = np.ones(I.size, dtype=bool)
+    new[1:] = (I[1:] != I[:-1]) | (J[1:] != J[:-1])
+    starts = np.flatnonzero(new)
+    vals = np.add.reduceat(V, starts)
+    rows, cols = I[starts], J[starts]
+    indptr = np.zeros(shape[0] + 1, dtype=np.int64)
+    np.add.at(indptr, rows + 1, 1)
+    indptr = np.cumsum(indptr)
+    m = sp.csr_matrix((vals, cols.astype(np.int64), indptr), shape=shape)
+    m.has_sorted_indices = True
+    return m
+
+
+def _accumulate(n, idx, vals, seq):
+    """b[idx] += vals applied in `seq` order (sequential accumulation per entry)."""
+    out = np.zeros(n)
+    if idx.size:
+        order = np.lexsort((seq, idx))
+        i, v = idx[order], vals[order]
+        new = np.ones(i.size, dtype=bool)
+        new[1:] = i[1:] != i[:-1]
+        starts = np.flatnonzero(new)
+        out[i[starts]] = np.add.reduceat(v, starts)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Full-system assembly (Fem/EllipticPde.jl:60-157 function coeff, :187-275 nodal coeff)
+# --------------------------------------------------------------------------------------
+def do_isotropic_elliptic_assembly(cells, points, dinds: DirichletInds, point_marker,
+                                   a: Coeff, f, uexact):
+    """Full Galerkin system on the non-Dirichlet nodes: returns (A csr, b)."""
+    K, be, ue = _element_terms(cells, points, a, f, uexact)
+    nel = cells.shape[1]
+    n = dinds.not_dirichlet_l2g.size
+    is_dir = point_marker.ravel()[cells] == 1       # (3, nel)
+    loc = dinds.not_dirichlet_g2l[cells]            # -1 on Dirichlet
+    I, J, V, S = [], [], [], []
+    bi, bv, bs = [], [], []
+    el = np.arange(nel)
+    for i in range(3):
+        for j in range(3):
+            both = ~is_dir[i] & ~is_dir[j]
+            I.append(loc[i][both]); J.append(loc[j][both]); V.append(K[i, j][both])
+            S.append(el[both] * 9 + i * 3 + j)
+            lift = is_dir[i] & ~is_dir[j]
+            bi.append(loc[j][lift]); bv.append(-(ue[i][lift] * K[i, j][lift]))
+            bs.append(el[lift] * 12 + i * 3 + j)
+    for i in range(3):
+        free = ~is_dir[i]
+        bi.append(loc[i][free]); bv.append(be[i][free]); bs.append(el[free] * 12 + 9 + i)
+    A = _coo_to_csr(np.concatenate(I), np.concatenate(J), np.concatenate(V), (n, n), np.concatenate(S))
+    b = _accumulate(n, np.concatenate(bi), np.concatenate(bv), np.concatenate(bs))
+    return A, b
+
+
+# --------------------------------------------------------------------------------------
+# prepare_local_schurs / prepare_global_schur (EPDD.jl:389-546 / 212-369)
+# --------------------------------------------------------------------------------------
+def _prepare(cells, points, epart, sub: Subdomains, coeff, f, uexact, local: bool):
+    K, be, ue = _element_terms(cells, points, coeff, f, uexact)
+    nel = cells.shape[1]
+    owner = sub.node_owner[cells]                   # (3, nel)
+    el = np.arange(nel)
+    n_Γ = sub.n_Γ
+    gΓ = sub.ind_Γ_g2l[cells]
+    gI = sub.ind_I_g2l[cells]
+    # Γ_d-local index of every (vertex, element): only meaningful where owner == -1
+    gΓd = np.full(cells.shape, -1, dtype=np.int64)
+    nnode = sub.node_owner.size
+    tmp = np.full(nnode, -1, dtype=np.int64)
+    for d in range(sub.ndom):
+        tmp[sub.node_Γd[d]] = np.arange(sub.node_Γd[d].size)
+        e = sub.elemd[d]
+        gΓd[:, e] = tmp[cells[:, e]]
+        tmp[sub.node_Γd[d]] = -1
+
+    A_II, A_IΓ, A_ΓΓ_parts = [], [], []
+    b_Id = []
+    bΓ_i, bΓ_v, bΓ_s = [], [], []
+    ΓΓ_glob = ([], [], [], [])
+    for d in range(sub.ndom):
+        e = sub.elemd[d]
+        ow, Ke, uee, bee = owner[:, e], K[:, :, e], ue[:, e], be[:, e]
+        gId, gΓe, gΓde, ele = gI[:, e], gΓ[:, e], gΓd[:, e], el[e]
+        II = ([], [], [], []); IΓ = ([], [], [], []); ΓΓ = ([], [], [], [])
+        bI = ([], [], [])
+        for i in range(3):
+            for j in range(3):
+                s = ele * 12 + i * 3 + j
+                oi, oj = ow[i], ow[j]
+                m = (oi == -1) & (oj == -1)
+                if local:
+                    ΓΓ[0].append(gΓde[i][m]); ΓΓ[1].append(gΓde[j][m])
+                    ΓΓ[2].append(Ke[i, j][m]); ΓΓ[3].append(s[m])
+                else:
+                    ΓΓ_glob[0].append(gΓe[i][m]); ΓΓ_glob[1].append(gΓe[j][m])
+                    ΓΓ_glob[2].append(Ke[i, j][m]); ΓΓ_glob[3].append(s[m])
+                m = (oi >= 0) & (oj >= 0)
+                II[0].append(gId[i][m]); II[1].append(gId[j][m]); II[2].append(Ke[i, j][m]); II[3].append(s[m])
+                m = (oi >= 0) & (oj == -1)
+                IΓ[0].append(gId[i][m]); IΓ[1].append((gΓde if local else gΓe)[j][m])
+                IΓ[2].append(Ke[i, j][m]); IΓ[3].append(s[m])
+                # Dirichlet lifting (EPDD.jl:322-331 / 498-507)
+                m = (oi == -2) & (oj == -1)
+                bΓ_i.append(gΓe[j][m]); bΓ_v.append(-(Ke[i, j][m] * uee[i][m])); bΓ_s.append(s[m])
+                m = (oi == -2) & (oj >= 0)
+                bI[0].append(gId[j][m]); bI[1].append(-(Ke[i, j][m] * uee[i][m])); bI[2].append(s[m])
+        for i in range(3):
+            s = ele * 12 + 9 + i
+            m = ow[i] == -1
+            bΓ_i.append(gΓe[i][m]); bΓ_v.append(bee[i][m]); bΓ_s.append(s[m])
+            m = ow[i] >= 0
+            bI[0].append(gId[i][m]); bI[1].append(bee[i][m]); bI[2].append(s[m])
+        nI, nΓd = sub.node_Id[d].size, sub.node_Γd[d].size
+        cat = np.concatenate
+        A_II.append(_coo_to_csr(cat(II[0]), cat(II[1]), cat(II[2]), (nI, nI), cat(II[3])))
+        A_IΓ.append(_coo_to_csr(cat(IΓ[0]), cat(IΓ[1]), cat(IΓ[2]), (nI, nΓd if local else n_Γ), cat(IΓ[3])))
+        if local:
+            A_ΓΓ_parts.append(_coo_to_csr(cat(ΓΓ[0]), cat(ΓΓ[1]), cat(ΓΓ[2]), (nΓd, nΓd), cat(ΓΓ[3])))
+        b_Id.append(_accumulate(nI, cat(bI[0]), cat(bI[1]), cat(bI[2])))
+    b_Γ = _accumulate(n_Γ, np.concatenate(bΓ_i), np.concatenate(bΓ_v), np.concatenate(bΓ_s))
+    if local:
+        return A_II, A_IΓ, A_ΓΓ_parts, b_Id, b_Γ
+    cat = np.concatenate
+    A_ΓΓ = _coo_to_csr(cat(ΓΓ_glob[0]), cat(ΓΓ_glob[1]), cat(ΓΓ_glob[2]), (n_Γ, n_Γ), cat(ΓΓ_glob[3]))
+    return A_II, A_IΓ, A_ΓΓ, b_Id, b_Γ
+
+
+def prepare_local_schurs(cells, points, epart, sub: Subdomains, coeff: Coeff, f, uexact):
+    """`prepare_local_schurs` (EPDD.jl:389-546): (A_IIdd, A_IΓdd, A_ΓΓdd, b_Id, b_Γ), Γ_d-local columns."""
+    return _prepare(cells, points, epart, sub, coeff, f, uexact, local=True)
+
+
+def prepare_global_schur(cells, points, epart, sub: Subdomains, coeff: Coeff, f, uexact):
+    """`prepare_global_schur` (EPDD.jl:212-369): (A_IId, A_IΓd, A_ΓΓ, b_Id, b_Γ), Γ-global columns."""
+    return _prepare(cells, points, epart, sub, coeff, f, uexact, local=False)
+
+
+# --------------------------------------------------------------------------------------
+# Interior solves and assembled local Schur complements
+# --------------------------------------------------------------------------------------
+class InteriorSolver:
+    """Host-side A_II^{-1} (sparse direct). Stands in for the reference's
+    `IterativeSolvers.cg(A_II, rhs; Pl=AMG, reltol)` (EPDD.jl:648-650) and is what
+    BASELINE.json's north_star calls "the host-side sparse Cholesky"."""
+
+    def __init__(self, A_II: sp.spmatrix):
+        self.n = A_II.shape[0]
+        self.lu = spla.splu(sp.csc_matrix(A_II), permc_spec="MMD_AT_PLUS_A",
+                            diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+
+    def __call__(self, rhs: np.ndarray) -> np.ndarray:
+        return self.lu.solve(np.ascontiguousarray(rhs, dtype=np.float64))
+
+
+def assemble_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, solvers: Optional[Sequence[InteriorSolver]] = None,
+                          chunk: int = 256):
+    """`assemble_local_schurs` (EPDD.jl:667-695): dense S_d = A_ΓΓd - A_IΓd' A_IId^{-1} A_IΓd.
+
+    The reference applies `apply_local_schur` to every unit vector and keeps the upper
+    triangle (`Symmetric(Array(map))`, :692); here the columns come from a multi-RHS
+    direct solve and the result is symmetrised the same way (upper triangle mirrored).
+    Returns column-major (Fortran-order) arrays like Julia's `Array`.
+    """
+    out = []
+    for d in range(len(A_IIdd)):
+        n = A_ΓΓdd[d].shape[0]
+        solve = solvers[d] if solvers is not None else InteriorSolver(A_IIdd[d])
+        S = np.asarray(A_ΓΓdd[d].todense(), dtype=np.float64)
+        AIΓ = sp.csc_matrix(A_IΓdd[d])
+        AΓI = sp.csr_matrix(A_IΓdd[d].T)
+        for c0 in range(0, n, chunk):
+            c1 = min(n, c0 + chunk)
+            V = solve(AIΓ[:, c0:c1].toarray())
+            S[:, c0:c1] -= AΓI @ V
+        S = np.triu(S) + np.triu(S, 1).T
+        out.append(np.asfortranarray(S))
+    return out
+
+
+def prepare_neumann_neumann_schur_precond(Sd: Sequence[np.ndarray]):
+    """`prepare_neumann_neumann_schur_precond(Sd_local_mat, ...)` (EPDD.jl:1201-1220):
+    ΠS_d = pinv(S_d, rtol = sqrt(eps(Float64)))."""
+    rtol = float(np.sqrt(np.finfo(np.float64).eps))
+    return [np.asfortranarray(np.linalg.pinv(np.asarray(S), rcond=rtol)) for S in Sd]
+
+
+def get_schur_rhs(b_Id, A_IId, A_IΓd, b_Γ, gather_idx=None, solvers=None):
+    """`get_schur_rhs` (EPDD.jl:798-821 global columns; :835-864 local columns + scatter)."""
+    b = np.array(b_Γ, dtype=np.float64, copy=True)
+    for d in range(len(b_Id)):
+        solve = solvers[d] if solvers is not None else InteriorSolver(A_IId[d])
+        w = A_IΓd[d].T @ solve(b_Id[d])
+        if gather_idx is None:
+            b -= w
+        else:
+            b[gather_idx[d]] -= w
+    return b
+
+
+def get_subdomain_solutions(u_Γ, A_IId, A_IΓd_global, b_Id, solvers=None):
+    """`get_subdomain_solutions` (EPDD.jl:1014-1025): u_I = A_II^{-1}(b_I - A_IΓ u_Γ)."""
+    out = []
+    for d in range(len(b_Id)):
+        solve = solvers[d] if solvers is not None else InteriorSolver(A_IId[d])
+        out.append(solve(b_Id[d] - A_IΓd_global[d] @ u_Γ))
+    return out
+
+
+def merge_subdomain_solutions(u_Γ, u_Id, sub: Subdomains, dinds: DirichletInds, uexact, points):
+    """`merge_subdomain_solutions` (EPDD.jl:1040-1070)."""
+    u = np.empty(points.shape[1])
+    u[sub.node_Γ] = u_Γ
+    for d in range(sub.ndom):
+        u[sub.node_Id[d]] = u_Id[d]
+    g = dinds.dirichlet_l2g
+    u[g] = _eval(uexact, points[0, g], points[1, g])
+    return u
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic lognormal coefficient (semantics of
+# `draw!` Fem/KarhunenLoeveDomainDecomposition.jl:1026-1044: g = Σ sqrt(Λ_α) ξ_α Ψ[:,α])
+# --------------------------------------------------------------------------------------
+@dataclass
+class SyntheticKL:
+    Λ: np.ndarray       # (m,)
+    Ψ: np.ndarray       # (nnode, m)
+
+
+def synthetic_kl(points, m_side: int = 8, L: float = 0.1, sig2: float = 1.0) -> SyntheticKL:
+    """Separable cosine modes Ψ_{kl} = cos(kπx)cos(lπy), Λ_{kl} ∝ exp(-(k²+l²)π²L²/4),
+    scaled so that Σ Λ = sig2; m = m_side² modes ordered by decreasing Λ (ties: k then l)."""
+    ks, ls = np.meshgrid(np.arange(m_side), np.arange(m_side), indexing="ij")
+    ks, ls = ks.ravel(), ls.ravel()
+    lam = np.exp(-(ks ** 2 + ls ** 2) * np.pi ** 2 * L ** 2 / 4)
+    order = np.lexsort((ls, ks, -lam))
+    ks, ls, lam = ks[order], ls[order], lam[order]
+    lam = lam * (sig2 / lam.sum())
+    x, y = points
+    Ψ = np.cos(np.pi * x[:, None] * ks[None, :]) * np.cos(np.pi * y[:, None] * ls[None, :])
+    return SyntheticKL(lam, Ψ)
+
+
+def draw(kl: SyntheticKL, rng: np.random.Generator):
+    """`draw!`: ξ ~ N(0, I); g = Σ_α sqrt(Λ_α) ξ_α Ψ[:,α] accumulated mode by mode."""
+    ξ = rng.standard_normal(kl.Λ.size)
+    g = np.zeros(kl.Ψ.shape[0])
+    for α in range(kl.Λ.size):
+        g += (np.sqrt(kl.Λ[α]) * ξ[α]) * kl.Ψ[:, α]
+    return ξ, g
+
+
+# --------------------------------------------------------------------------------------
+# One-call problem builders used by tests, smoke() and bench.py
+# --------------------------------------------------------------------------------------
+@dataclass
+class SchurProblem:
+    mesh: Mesh
+    dinds: DirichletInds
+    sub: Subdomains
+    epart: np.ndarray
+    A_IIdd: list
+    A_IΓdd: list
+    A_ΓΓdd: list
+    b_Id: list
+    b_Γ: np.ndarray
+    b_schur: np.ndarray
+    Sd: Optional[list] = None       # dense local Schur complements, column-major
+    ΠSd: Optional[list] = None      # their pseudo-inverses, column-major
+    solvers: Optional[list] = None
+    uexact: Optional[Callable] = None
+    info: dict = field(default_factory=dict)
+
+
+def build_schur_problem(N: int, px: int, py: int, coeff: Coeff, f, uexact,
+                        assemble: bool = True, precond: bool = True) -> SchurProblem:
+    """Example03:45-150 set-up flow on the synthetic mesh (mesh → partition → maps →
+    local blocks → b_schur → assembled S_d → Neumann-Neumann pseudo-inverses)."""
+    mesh = get_mesh(N)
+    dinds = get_dirichlet_inds(mesh.points, mesh.point_marker)
+    epart, npart = mesh_partition(mesh, px, py)
+    sub = set_subdomains(mesh.cells, mesh.cell_neighbors, epart, npart, dinds.dirichlet_g2l)
+    if callable(coeff) and getattr(coeff, "_wants_points", False):
+        coeff = coeff(mesh.points)
+    A_II, A_IΓ, A_ΓΓ, b_Id, b_Γ = prepare_local_schurs(mesh.cells, mesh.points, epart, sub, coeff, f, uexact)
+    solvers = [InteriorSolver(A) for A in A_II]
+    b_schur = get_schur_rhs(b_Id, A_II, A_IΓ, b_Γ, sub.gather_idx, solvers)
+    prob = SchurProblem(mesh, dinds, sub, epart, A_II, A_IΓ, A_ΓΓ, b_Id, b_Γ, b_schur,
+                        solvers=solvers, uexact=uexact)
+    if assemble:
+        prob.Sd = assemble_local_schurs(A_II, A_IΓ, A_ΓΓ, solvers)
+        if precond:
+            prob.ΠSd = prepare_neumann_neumann_schur_precond(prob.Sd)
+    return prob

@@ -1,0 +1,533 @@
+/* TEST INFRASTRUCTURE — NOT PART OF THE PRODUCT.
+ *
+ * CPU fp64 restatement of the Schur-PCG hot path of venkovic/julia-phd-krylov-spdes, used
+ * only as the checker in tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg.
+ * Nothing under julia-phd-krylov-spdes_amd/ links, loads or calls this file.
+ *
+ * PARITY UNPINNED: the reference has no tests, golden vectors or stored outputs for this
+ * path and cannot be run here (no `julia`). This restatement is pinned
+ * by (1) the recurrences and stopping rule transcribed below, (2) the identities the
+ * reference itself prints (Example03:175, :204) and (3) known-answer tests in tests/.
+ *
+ * Citations are relative to /root/reference. "EPDD.jl" = Fem/EllipticPdeDomainDecomposition.jl.
+ * Third-party arithmetic that is not under /root/reference and is restated from its
+ * published semantics: Julia 1.5 stdlib SparseArrays (CSC `A*x`, `A'*v`), LinearAlgebra /
+ * OpenBLAS (`dot`, `axpy!`, `axpby!`, `norm2`, `gemv`, dense `\` = LU with partial
+ * pivoting). Reduction order inside OpenBLAS is unspecified; here every reduction is a
+ * plain left-to-right sum. Build with -ffp-contract=off (no FMA contraction), as Julia
+ * does not contract `a*b+c` either.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef int64_t i64;
+
+/* ------------------------------------------------------------------ BLAS-1 (RecyclingKrylovSolvers.jl:3) */
+double orc_dot(i64 n, const double *x, const double *y) {
+  double s = 0.0;
+  for (i64 i = 0; i < n; ++i) s += x[i] * y[i];
+  return s;
+}
+double orc_norm2(i64 n, const double *x) { return sqrt(orc_dot(n, x, x)); }
+/* y += a*x */
+void orc_axpy(i64 n, double a, const double *x, double *y) {
+  for (i64 i = 0; i < n; ++i) y[i] = y[i] + a * x[i];
+}
+/* y = a*x + b*y */
+void orc_axpby(i64 n, double a, const double *x, double b, double *y) {
+  for (i64 i = 0; i < n; ++i) y[i] = a * x[i] + b * y[i];
+}
+
+/* ------------------------------------------------------------------ sparse mat-vec (stdlib SparseArrays) */
+/* y = A*x for CSC A (m x n): column scatter, `y[rowval[k]] += nzval[k]*x[j]`, j ascending. */
+void orc_csc_spmv(i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
+                  const double *x, double *y) {
+  for (i64 i = 0; i < m; ++i) y[i] = 0.0;
+  for (i64 j = 0; j < n; ++j) {
+    double xj = x[j];
+    for (i64 k = colptr[j]; k < colptr[j + 1]; ++k) y[rowval[k]] += nzval[k] * xj;
+  }
+}
+/* y = A'*v for CSC A (m x n)  ==  CSR row gather on the same arrays: y[j] = sum_k nzval[k]*v[rowval[k]]. */
+void orc_csc_spmv_t(i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
+                    const double *v, double *y) {
+  (void)m;
+#pragma omp parallel for schedule(static)
+  for (i64 j = 0; j < n; ++j) {
+    double s = 0.0;
+    for (i64 k = colptr[j]; k < colptr[j + 1]; ++k) s += nzval[k] * v[rowval[k]];
+    y[j] = s;
+  }
+}
+/* dense column-major y = M*x (n x n, leading dimension n): column-axpy order, which is also the
+ * order of the CSC SpMV the reference runs on its fully dense `Sd[idom]` (EPDD.jl:778). */
+void orc_gemv_colmajor(i64 m, i64 n, const double *M, const double *x, double *y) {
+#pragma omp parallel
+  {
+    i64 nt = 1, tid = 0;
+#ifdef _OPENMP
+    extern int omp_get_num_threads(void);
+    extern int omp_get_thread_num(void);
+    nt = omp_get_num_threads();
+    tid = omp_get_thread_num();
+#endif
+    i64 r0 = m * tid / nt, r1 = m * (tid + 1) / nt;
+    for (i64 i = r0; i < r1; ++i) y[i] = 0.0;
+    for (i64 j = 0; j < n; ++j) {
+      double xj = x[j];
+      const double *col = M + j * m;
+      for (i64 i = r0; i < r1; ++i) y[i] += col[i] * xj;
+    }
+  }
+}
+/* y = M'*x for column-major M (m x n): y[j] = M[:,j] . x */
+void orc_gemv_colmajor_t(i64 m, i64 n, const double *M, const double *x, double *y) {
+  for (i64 j = 0; j < n; ++j) y[j] = orc_dot(m, M + j * m, x);
+}
+
+/* ------------------------------------------------------------------ operators */
+typedef void (*orc_apply_fn)(void *ctx, const double *x, double *y);
+typedef void (*orc_interior_cb)(void *user, i64 idom, i64 n, const double *rhs, double *sol);
+
+typedef struct {
+  orc_apply_fn apply;
+  void *ctx;
+  i64 n;
+} orc_op;
+
+void orc_op_apply(const orc_op *op, const double *x, double *y) { op->apply(op->ctx, x, y); }
+void orc_op_free(orc_op *op) {
+  if (op) {
+    free(op->ctx);
+    free(op);
+  }
+}
+static orc_op *mk_op(orc_apply_fn f, void *ctx, i64 n) {
+  orc_op *op = (orc_op *)malloc(sizeof(orc_op));
+  op->apply = f;
+  op->ctx = ctx;
+  op->n = n;
+  return op;
+}
+
+/* -- symmetric sparse matrix given by its CSC (== CSR) arrays; `A*x` as the stdlib does it. */
+typedef struct {
+  i64 n;
+  const i64 *ptr, *idx;
+  const double *val;
+  int gather; /* 1: row-gather form (parallel, same per-row order for symmetric A) */
+} csc_ctx;
+static void csc_apply(void *c_, const double *x, double *y) {
+  csc_ctx *c = (csc_ctx *)c_;
+  if (c->gather)
+    orc_csc_spmv_t(c->n, c->n, c->ptr, c->idx, c->val, x, y);
+  else
+    orc_csc_spmv(c->n, c->n, c->ptr, c->idx, c->val, x, y);
+}
+orc_op *orc_csc_op(i64 n, const i64 *colptr, const i64 *rowval, const double *nzval, int gather) {
+  csc_ctx *c = (csc_ctx *)malloc(sizeof(csc_ctx));
+  c->n = n; c->ptr = colptr; c->idx = rowval; c->val = nzval; c->gather = gather;
+  return mk_op(csc_apply, c, n);
+}
+
+/* -- identity and Jacobi `M \ r` */
+typedef struct { i64 n; const double *dinv; } diag_ctx;
+static void diag_apply(void *c_, const double *x, double *y) {
+  diag_ctx *c = (diag_ctx *)c_;
+  if (c->dinv) for (i64 i = 0; i < c->n; ++i) y[i] = c->dinv[i] * x[i];
+  else memcpy(y, x, sizeof(double) * (size_t)c->n);
+}
+orc_op *orc_diag_op(i64 n, const double *dinv) {
+  diag_ctx *c = (diag_ctx *)malloc(sizeof(diag_ctx));
+  c->n = n; c->dinv = dinv;
+  return mk_op(diag_apply, c, n);
+}
+
+/* -- apply_local_schurs, assembled (EPDD.jl:761-785):
+ *    Sx = 0; for idom: xd[lΓd] = x[lΓ]; Sdxd = Sd[idom]*xd; Sx[lΓ] += Sdxd[lΓd]. */
+typedef struct {
+  i64 ndom, n_gamma, maxd;
+  const i64 *n_d;
+  const i64 *const *gidx;
+  const double *const *Sd; /* column-major n_d x n_d */
+  double *xd, *yd;
+} sloc_ctx;
+static void sloc_apply(void *c_, const double *x, double *Sx) {
+  sloc_ctx *c = (sloc_ctx *)c_;
+  for (i64 i = 0; i < c->n_gamma; ++i) Sx[i] = 0.0;
+  for (i64 d = 0; d < c->ndom; ++d) {
+    i64 nd = c->n_d[d];
+    const i64 *g = c->gidx[d];
+    for (i64 l = 0; l < nd; ++l) c->xd[l] = x[g[l]];
+    orc_gemv_colmajor(nd, nd, c->Sd[d], c->xd, c->yd);
+    for (i64 l = 0; l < nd; ++l) Sx[g[l]] += c->yd[l];
+  }
+}
+static void sloc_free_extra(sloc_ctx *c) { free(c->xd); free(c->yd); }
+orc_op *orc_schur_assembled_op(i64 ndom, i64 n_gamma, const i64 *n_d, const i64 *const *gidx,
+                               const double *const *Sd) {
+  sloc_ctx *c = (sloc_ctx *)malloc(sizeof(sloc_ctx));
+  c->ndom = ndom; c->n_gamma = n_gamma; c->n_d = n_d; c->gidx = gidx; c->Sd = Sd;
+  c->maxd = 0;
+  for (i64 d = 0; d < ndom; ++d) if (n_d[d] > c->maxd) c->maxd = n_d[d];
+  c->xd = (double *)malloc(sizeof(double) * (size_t)(c->maxd + 1));
+  c->yd = (double *)malloc(sizeof(double) * (size_t)(c->maxd + 1));
+  (void)sloc_free_extra;
+  return mk_op(sloc_apply, c, n_gamma);
+}
+
+/* -- apply_neumann_neumann_schur (EPDD.jl:1361-1386):
+ *    z = 0; for idom: rd[lΓd] = r[lΓ]/cnt[lΓ]; t = ΠSd[idom]*rd; z[lΓ] += t[lΓd]/cnt[lΓ]. */
+typedef struct {
+  sloc_ctx s;
+  const i64 *cnt;
+} nn_ctx;
+static void nn_apply(void *c_, const double *r, double *z) {
+  nn_ctx *c = (nn_ctx *)c_;
+  for (i64 i = 0; i < c->s.n_gamma; ++i) z[i] = 0.0;
+  for (i64 d = 0; d < c->s.ndom; ++d) {
+    i64 nd = c->s.n_d[d];
+    const i64 *g = c->s.gidx[d];
+    for (i64 l = 0; l < nd; ++l) c->s.xd[l] = r[g[l]] / (double)c->cnt[g[l]];
+    orc_gemv_colmajor(nd, nd, c->s.Sd[d], c->s.xd, c->s.yd);
+    for (i64 l = 0; l < nd; ++l) z[g[l]] += c->s.yd[l] / (double)c->cnt[g[l]];
+  }
+}
+orc_op *orc_nn_op(i64 ndom, i64 n_gamma, const i64 *n_d, const i64 *const *gidx,
+                  const double *const *PiSd, const i64 *cnt) {
+  nn_ctx *c = (nn_ctx *)malloc(sizeof(nn_ctx));
+  c->s.ndom = ndom; c->s.n_gamma = n_gamma; c->s.n_d = n_d; c->s.gidx = gidx; c->s.Sd = PiSd;
+  c->s.maxd = 0;
+  for (i64 d = 0; d < ndom; ++d) if (n_d[d] > c->s.maxd) c->s.maxd = n_d[d];
+  c->s.xd = (double *)malloc(sizeof(double) * (size_t)(c->s.maxd + 1));
+  c->s.yd = (double *)malloc(sizeof(double) * (size_t)(c->s.maxd + 1));
+  c->cnt = cnt;
+  return mk_op(nn_apply, c, n_gamma);
+}
+
+/* -- apply_local_schur / apply_local_schurs, matrix-free (EPDD.jl:639-654, 711-747):
+ *    Sdxd = A_ΓΓdd*xd - A_IΓdd' * (A_IIdd^{-1} (A_IΓdd*xd)); interior solve = callback.
+ *    A_IΓdd is CSC (n_Id x n_Γd); A_ΓΓdd is CSC symmetric. */
+typedef struct {
+  i64 ndom, n_gamma;
+  const i64 *n_d, *n_i;
+  const i64 *const *gidx;
+  const i64 *const *ig_ptr; const i64 *const *ig_idx; const double *const *ig_val; /* A_IΓdd CSC */
+  const i64 *const *gg_ptr; const i64 *const *gg_idx; const double *const *gg_val; /* A_ΓΓdd CSC */
+  orc_interior_cb solve; void *user;
+  double *xd, *yd, *td, *rhs, *sol;
+} mf_ctx;
+static void mf_apply(void *c_, const double *x, double *Sx) {
+  mf_ctx *c = (mf_ctx *)c_;
+  for (i64 i = 0; i < c->n_gamma; ++i) Sx[i] = 0.0;
+  for (i64 d = 0; d < c->ndom; ++d) {
+    i64 nd = c->n_d[d], ni = c->n_i[d];
+    const i64 *g = c->gidx[d];
+    for (i64 l = 0; l < nd; ++l) c->xd[l] = x[g[l]];
+    orc_csc_spmv(nd, nd, c->gg_ptr[d], c->gg_idx[d], c->gg_val[d], c->xd, c->yd);
+    orc_csc_spmv(ni, nd, c->ig_ptr[d], c->ig_idx[d], c->ig_val[d], c->xd, c->rhs);
+    c->solve(c->user, d, ni, c->rhs, c->sol);
+    orc_csc_spmv_t(ni, nd, c->ig_ptr[d], c->ig_idx[d], c->ig_val[d], c->sol, c->td);
+    for (i64 l = 0; l < nd; ++l) c->yd[l] = c->yd[l] - c->td[l];
+    for (i64 l = 0; l < nd; ++l) Sx[g[l]] += c->yd[l];
+  }
+}
+orc_op *orc_schur_matfree_op(i64 ndom, i64 n_gamma, const i64 *n_d, const i64 *n_i, const i64 *const *gidx,
+                             const i64 *const *ig_ptr, const i64 *const *ig_idx, const double *const *ig_val,
+                             const i64 *const *gg_ptr, const i64 *const *gg_idx, const double *const *gg_val,
+                             orc_interior_cb solve, void *user) {
+  mf_ctx *c = (mf_ctx *)malloc(sizeof(mf_ctx));
+  c->ndom = ndom; c->n_gamma = n_gamma; c->n_d = n_d; c->n_i = n_i; c->gidx = gidx;
+  c->ig_ptr = ig_ptr; c->ig_idx = ig_idx; c->ig_val = ig_val;
+  c->gg_ptr = gg_ptr; c->gg_idx = gg_idx; c->gg_val = gg_val;
+  c->solve = solve; c->user = user;
+  i64 md = 0, mi = 0;
+  for (i64 d = 0; d < ndom; ++d) { if (n_d[d] > md) md = n_d[d]; if (n_i[d] > mi) mi = n_i[d]; }
+  c->xd = (double *)malloc(sizeof(double) * (size_t)(md + 1));
+  c->yd = (double *)malloc(sizeof(double) * (size_t)(md + 1));
+  c->td = (double *)malloc(sizeof(double) * (size_t)(md + 1));
+  c->rhs = (double *)malloc(sizeof(double) * (size_t)(mi + 1));
+  c->sol = (double *)malloc(sizeof(double) * (size_t)(mi + 1));
+  return mk_op(mf_apply, c, n_gamma);
+}
+
+/* -- apply_global_schur (EPDD.jl:596-625): Sx = A_ΓΓ*x; for idom: v = A_II^{-1}(A_IΓd*x); Sx -= A_IΓd'*v.
+ *    A_IΓd is CSC (n_Id x n_Γ), Γ-global columns; A_ΓΓ is CSC symmetric (n_Γ x n_Γ). */
+typedef struct {
+  i64 ndom, n_gamma;
+  const i64 *n_i;
+  const i64 *const *ig_ptr; const i64 *const *ig_idx; const double *const *ig_val;
+  const i64 *gg_ptr; const i64 *gg_idx; const double *gg_val;
+  orc_interior_cb solve; void *user;
+  double *t, *rhs, *sol;
+} gs_ctx;
+static void gs_apply(void *c_, const double *x, double *Sx) {
+  gs_ctx *c = (gs_ctx *)c_;
+  orc_csc_spmv(c->n_gamma, c->n_gamma, c->gg_ptr, c->gg_idx, c->gg_val, x, Sx);
+  for (i64 d = 0; d < c->ndom; ++d) {
+    i64 ni = c->n_i[d];
+    orc_csc_spmv(ni, c->n_gamma, c->ig_ptr[d], c->ig_idx[d], c->ig_val[d], x, c->rhs);
+    c->solve(c->user, d, ni, c->rhs, c->sol);
+    orc_csc_spmv_t(ni, c->n_gamma, c->ig_ptr[d], c->ig_idx[d], c->ig_val[d], c->sol, c->t);
+    for (i64 i = 0; i < c->n_gamma; ++i) Sx[i] = Sx[i] - c->t[i];
+  }
+}
+orc_op *orc_schur_global_op(i64 ndom, i64 n_gamma, const i64 *n_i,
+                            const i64 *const *ig_ptr, const i64 *const *ig_idx, const double *const *ig_val,
+                            const i64 *gg_ptr, const i64 *gg_idx, const double *gg_val,
+                            orc_interior_cb solve, void *user) {
+  gs_ctx *c = (gs_ctx *)malloc(sizeof(gs_ctx));
+  c->ndom = ndom; c->n_gamma = n_gamma; c->n_i = n_i;
+  c->ig_ptr = ig_ptr; c->ig_idx = ig_idx; c->ig_val = ig_val;
+  c->gg_ptr = gg_ptr; c->gg_idx = gg_idx; c->gg_val = gg_val;
+  c->solve = solve; c->user = user;
+  i64 mi = 0;
+  for (i64 d = 0; d < ndom; ++d) if (n_i[d] > mi) mi = n_i[d];
+  c->t = (double *)malloc(sizeof(double) * (size_t)(n_gamma + 1));
+  c->rhs = (double *)malloc(sizeof(double) * (size_t)(mi + 1));
+  c->sol = (double *)malloc(sizeof(double) * (size_t)(mi + 1));
+  return mk_op(gs_apply, c, n_gamma);
+}
+
+/* ------------------------------------------------------------------ dense `A \ b` (LU, partial pivoting) */
+/* LAPACK dgetf2/dgetrs semantics on a column-major n x n copy. Returns 0, or k+1 if U[k,k]==0
+ * (Julia throws SingularException(k+1)). */
+int orc_lu_solve(i64 n, const double *A, double *b) {
+  double *a = (double *)malloc(sizeof(double) * (size_t)(n * n + 1));
+  memcpy(a, A, sizeof(double) * (size_t)(n * n));
+  int info = 0;
+  for (i64 k = 0; k < n; ++k) {
+    i64 p = k; double mx = fabs(a[k + k * n]);
+    for (i64 i = k + 1; i < n; ++i) { double v = fabs(a[i + k * n]); if (v > mx) { mx = v; p = i; } }
+    if (a[p + k * n] == 0.0) { if (!info) info = (int)(k + 1); continue; }
+    if (p != k) {
+      for (i64 j = 0; j < n; ++j) { double t = a[k + j * n]; a[k + j * n] = a[p + j * n]; a[p + j * n] = t; }
+      double t = b[k]; b[k] = b[p]; b[p] = t;
+    }
+    double piv = 1.0 / a[k + k * n];
+    for (i64 i = k + 1; i < n; ++i) a[i + k * n] *= piv;
+    for (i64 j = k + 1; j < n; ++j) {
+      double akj = a[k + j * n];
+      for (i64 i = k + 1; i < n; ++i) a[i + j * n] -= a[i + k * n] * akj;
+    }
+  }
+  if (info) { free(a); return info; }
+  /* forward (unit lower; b was permuted as the factorisation went) */
+  for (i64 k = 0; k < n; ++k) {
+    double bk = b[k];
+    for (i64 i = k + 1; i < n; ++i) b[i] -= bk * a[i + k * n];
+  }
+  /* backward */
+  for (i64 k = n - 1; k >= 0; --k) {
+    b[k] /= a[k + k * n];
+    double bk = b[k];
+    for (i64 i = 0; i < k; ++i) b[i] -= bk * a[i + k * n];
+  }
+  free(a);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ solvers */
+#define ORC_EPS_DEFAULT 1e-7 /* RecyclingKrylovSolvers.jl:21 */
+
+/* cg (cg.jl:14-50). res_norm must hold n entries (cg.jl:23). Returns it. */
+i64 orc_cg(const orc_op *A, const double *b, double *x, i64 maxit, double eps, double *res_norm) {
+  i64 n = A->n;
+  double *r = (double *)malloc(sizeof(double) * (size_t)n * 3);
+  double *p = r + n, *Ap = p + n;
+  if (maxit == 0) maxit = n;
+  i64 it = 1;
+  orc_op_apply(A, x, Ap);
+  for (i64 i = 0; i < n; ++i) r[i] = b[i] - Ap[i];
+  double rTr = orc_dot(n, r, r);
+  memcpy(p, r, sizeof(double) * (size_t)n);
+  res_norm[it - 1] = sqrt(rTr);
+  double tol = eps * orc_norm2(n, b);
+  while (it < maxit && res_norm[it - 1] > tol) {
+    orc_op_apply(A, p, Ap);
+    double d = orc_dot(n, p, Ap);
+    double alpha = rTr / d;
+    double beta = 1. / rTr;
+    orc_axpy(n, alpha, p, x);
+    orc_axpy(n, -alpha, Ap, r);
+    rTr = orc_dot(n, r, r);
+    beta *= rTr;
+    orc_axpby(n, 1.0, r, beta, p);
+    it += 1;
+    res_norm[it - 1] = sqrt(rTr);
+  }
+  free(r);
+  return it;
+}
+
+/* pcg (cg.jl:67-109). */
+i64 orc_pcg(const orc_op *A, const orc_op *M, const double *b, double *x, i64 maxit, double eps,
+            double *res_norm) {
+  i64 n = A->n;
+  double *r = (double *)malloc(sizeof(double) * (size_t)n * 4);
+  double *z = r + n, *p = z + n, *Ap = p + n;
+  if (maxit == 0) maxit = n;
+  i64 it = 1;
+  orc_op_apply(A, x, Ap);
+  for (i64 i = 0; i < n; ++i) r[i] = b[i] - Ap[i];
+  double rTr = orc_dot(n, r, r);
+  orc_op_apply(M, r, z);
+  double rTz = orc_dot(n, r, z);
+  memcpy(p, z, sizeof(double) * (size_t)n);
+  res_norm[it - 1] = sqrt(rTr);
+  double tol = eps * orc_norm2(n, b);
+  while (it < maxit && res_norm[it - 1] > tol) {
+    orc_op_apply(A, p, Ap);
+    double d = orc_dot(n, p, Ap);
+    double alpha = rTz / d;
+    double beta = 1. / rTz;
+    orc_axpy(n, alpha, p, x);
+    orc_axpy(n, -alpha, Ap, r);
+    rTr = orc_dot(n, r, r);
+    orc_op_apply(M, r, z);
+    rTz = orc_dot(n, r, z);
+    beta *= rTz;
+    orc_axpby(n, 1.0, z, beta, p);
+    it += 1;
+    res_norm[it - 1] = sqrt(rTr);
+  }
+  free(r);
+  return it;
+}
+
+/* Shared deflation set-up (defcg.jl:41-54 / 261-275): WtA rows = A*W[:,i] (the FunctionMap branch;
+ * the SparseMatrixCSC branch `mul!(WtA, W', A)` is the same numbers for symmetric A up to summation
+ * order), WtAW = WtA*W, x += W*(WtAW \ (W'r)). W is n x nvec column-major; WtA is nvec x n column-major.
+ * Returns 0 or the SingularException index. */
+static int defl_setup(const orc_op *A, const double *b, double *x, const double *W, i64 nvec,
+                      double *WtA, double *WtAW, double *r, double *Ap, double *mu, double *tmp) {
+  i64 n = A->n;
+  for (i64 v = 0; v < nvec; ++v) {
+    orc_op_apply(A, W + v * n, tmp);
+    for (i64 j = 0; j < n; ++j) WtA[v + j * nvec] = tmp[j];
+  }
+  /* WtAW = WtA * W (nvec x nvec), textbook gemm, k innermost */
+  for (i64 i = 0; i < nvec; ++i)
+    for (i64 j = 0; j < nvec; ++j) {
+      double s = 0.0;
+      for (i64 k = 0; k < n; ++k) s += WtA[i + k * nvec] * W[k + j * n];
+      WtAW[i + j * nvec] = s;
+    }
+  orc_op_apply(A, x, Ap);
+  for (i64 i = 0; i < n; ++i) r[i] = b[i] - Ap[i];
+  orc_gemv_colmajor_t(n, nvec, W, r, mu);           /* mu = W'r */
+  int info = orc_lu_solve(nvec, WtAW, mu);          /* mu = WtAW \ mu */
+  if (info) return info;
+  for (i64 i = 0; i < n; ++i) tmp[i] = 0.0;
+  for (i64 v = 0; v < nvec; ++v) orc_axpy(n, mu[v], W + v * n, tmp); /* W*mu */
+  for (i64 i = 0; i < n; ++i) x[i] = x[i] + tmp[i];
+  return 0;
+}
+/* mu = WtAW \ (WtA*v);  out = W*mu */
+static int defl_project(i64 n, i64 nvec, const double *WtA, const double *WtAW, const double *W,
+                        const double *v, double *mu, double *out) {
+  for (i64 i = 0; i < nvec; ++i) mu[i] = 0.0;
+  for (i64 j = 0; j < n; ++j) {                      /* gemv N on nvec x n column-major */
+    double vj = v[j];
+    for (i64 i = 0; i < nvec; ++i) mu[i] += WtA[i + j * nvec] * vj;
+  }
+  int info = orc_lu_solve(nvec, WtAW, mu);
+  if (info) return info;
+  for (i64 i = 0; i < n; ++i) out[i] = 0.0;
+  for (i64 k = 0; k < nvec; ++k) orc_axpy(n, mu[k], W + k * n, out);
+  return 0;
+}
+
+/* defcg (defcg.jl:24-83). Returns it (>0) or -(singular index). */
+i64 orc_defcg(const orc_op *A, const double *b, double *x, const double *W, i64 nvec, i64 maxit,
+              double eps, double *res_norm) {
+  i64 n = A->n;
+  double *buf = (double *)malloc(sizeof(double) * (size_t)(4 * n + nvec * n + nvec * nvec + nvec + 8));
+  double *r = buf, *p = r + n, *Ap = p + n, *Wmu = Ap + n, *WtA = Wmu + n, *WtAW = WtA + nvec * n,
+         *mu = WtAW + nvec * nvec;
+  int info = defl_setup(A, b, x, W, nvec, WtA, WtAW, r, Ap, mu, Wmu);
+  if (info) { free(buf); return -(i64)info; }
+  if (maxit == 0) maxit = n;
+  i64 it = 1;
+  orc_op_apply(A, x, Ap);
+  for (i64 i = 0; i < n; ++i) r[i] = b[i] - Ap[i];
+  double rTr = orc_dot(n, r, r);
+  info = defl_project(n, nvec, WtA, WtAW, W, r, mu, Wmu);
+  if (info) { free(buf); return -(i64)info; }
+  for (i64 i = 0; i < n; ++i) p[i] = r[i] - Wmu[i];
+  res_norm[it - 1] = sqrt(rTr);
+  double tol = eps * orc_norm2(n, b);
+  while (it < maxit && res_norm[it - 1] > tol) {
+    orc_op_apply(A, p, Ap);
+    double d = orc_dot(n, p, Ap);
+    double alpha = rTr / d;
+    double beta = 1. / rTr;
+    orc_axpy(n, alpha, p, x);
+    orc_axpy(n, -alpha, Ap, r);
+    rTr = orc_dot(n, r, r);
+    beta *= rTr;
+    info = defl_project(n, nvec, WtA, WtAW, W, r, mu, Wmu);
+    if (info) { free(buf); return -(i64)info; }
+    for (i64 i = 0; i < n; ++i) p[i] = (beta * p[i] + r[i]) - Wmu[i];
+    it += 1;
+    res_norm[it - 1] = sqrt(rTr);
+  }
+  free(buf);
+  return it;
+}
+
+/* defpcg (defcg.jl:242-308), argument order (A,b,x,W,M). */
+i64 orc_defpcg(const orc_op *A, const orc_op *M, const double *b, double *x, const double *W, i64 nvec,
+               i64 maxit, double eps, double *res_norm) {
+  i64 n = A->n;
+  double *buf = (double *)malloc(sizeof(double) * (size_t)(5 * n + nvec * n + nvec * nvec + nvec + 8));
+  double *r = buf, *p = r + n, *Ap = p + n, *Wmu = Ap + n, *z = Wmu + n, *WtA = z + n,
+         *WtAW = WtA + nvec * n, *mu = WtAW + nvec * nvec;
+  int info = defl_setup(A, b, x, W, nvec, WtA, WtAW, r, Ap, mu, Wmu);
+  if (info) { free(buf); return -(i64)info; }
+  if (maxit == 0) maxit = n;
+  i64 it = 1;
+  orc_op_apply(A, x, Ap);
+  for (i64 i = 0; i < n; ++i) r[i] = b[i] - Ap[i];
+  double rTr = orc_dot(n, r, r);
+  res_norm[it - 1] = sqrt(rTr);
+  orc_op_apply(M, r, z);
+  double rTz = orc_dot(n, r, z);
+  info = defl_project(n, nvec, WtA, WtAW, W, z, mu, Wmu);
+  if (info) { free(buf); return -(i64)info; }
+  for (i64 i = 0; i < n; ++i) p[i] = z[i] - Wmu[i];
+  double tol = eps * orc_norm2(n, b);
+  while (it < maxit && res_norm[it - 1] > tol) {
+    orc_op_apply(A, p, Ap);
+    double d = orc_dot(n, p, Ap);
+    double alpha = rTz / d;
+    double beta = 1. / rTz;
+    orc_axpy(n, alpha, p, x);
+    orc_axpy(n, -alpha, Ap, r);
+    rTr = orc_dot(n, r, r);
+    orc_op_apply(M, r, z);
+    rTz = orc_dot(n, r, z);
+    beta *= rTz;
+    info = defl_project(n, nvec, WtA, WtAW, W, z, mu, Wmu);
+    if (info) { free(buf); return -(i64)info; }
+    for (i64 i = 0; i < n; ++i) p[i] = (beta * p[i] + z[i]) - Wmu[i];
+    it += 1;
+    res_norm[it - 1] = sqrt(rTr);
+  }
+  free(buf);
+  return it;
+}
+
+int orc_set_threads(int nt) {
+#ifdef _OPENMP
+  extern void omp_set_num_threads(int);
+  extern int omp_get_max_threads(void);
+  if (nt > 0) omp_set_num_threads(nt);
+  return omp_get_max_threads();
+#else
+  (void)nt;
+  return 1;
+#endif
+}

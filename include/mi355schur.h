@@ -1,0 +1,181 @@
+/* mi355schur.h — C ABI of libmi355schur: the MI355X (gfx950) Schur-complement PCG hot path.
+ *
+ * Drop-in boundary for the domain-decomposition hot path of venkovic/julia-phd-krylov-spdes.
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * reference root; "EPDD.jl" = Fem/EllipticPdeDomainDecomposition.jl). The reference is pure
+ * Julia: a `ccall` shim (julia/MI355Schur.jl, shown in INTEGRATION.md) binds exactly these
+ * symbols and re-exports the reference's own function names on top of them.
+ *
+ * Conventions
+ *   - Plain C: opaque handles, pointers and sizes. No C++ / torch types cross this ABI.
+ *   - Every function returns an int status: MI_OK (0) or a negative MI_ERR_* code;
+ *     mi_last_error() returns a thread-local description of the last failure. No exception
+ *     crosses the ABI (Julia side turns non-zero into `error(...)`; MI_ERR_SINGULAR maps to
+ *     LinearAlgebra.SingularException as thrown by `WtAW \ mu`, defcg.jl:53,273).
+ *   - Arithmetic is IEEE fp64 throughout; indices passed in are int64 with an explicit
+ *     `index_base` (1 for Julia arrays, 0 for C/numpy); they are stored as int32 on the device.
+ *   - `*_create` functions read HOST arrays and copy what they need to the device; the caller
+ *     keeps ownership and may free or mutate its arrays afterwards (Julia GC owns them).
+ *   - Vector arguments of apply/solve calls (`x`, `y`, `b`, `W`) are host pointers by default,
+ *     or device pointers after mi_ctx_set_pointer_mode(ctx, MI_PTR_DEVICE). Scalar/history
+ *     outputs (`it`, `res_norm`, dot results) are always host pointers.
+ *   - A context owns one HIP stream; handles are thread-compatible, not thread-safe. In
+ *     multi-GPU use there is one process (or thread) and one context per GPU and every rank
+ *     enters collective calls (anything on a handle created with n_ranks > 1) together.
+ *   - There is no CPU fallback: with no gfx950 device mi_ctx_create fails with MI_ERR_NO_DEVICE.
+ */
+#ifndef MI355SCHUR_H
+#define MI355SCHUR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_ERR_BAD_ARG (-1)      /* NULL/negative/out-of-range argument, index out of bounds          */
+#define MI_ERR_HIP (-2)          /* a HIP runtime call failed                                          */
+#define MI_ERR_SINGULAR (-3)     /* WtAW is singular to working precision (Julia: SingularException)   */
+#define MI_ERR_RES_CAPACITY (-4) /* res_norm capacity exhausted (Julia: BoundsError on res_norm[it])   */
+#define MI_ERR_COMM (-5)         /* RCCL not loadable / communicator failure                           */
+#define MI_ERR_NO_DEVICE (-6)    /* no usable gfx950 device                                            */
+#define MI_ERR_CALLBACK (-7)     /* the interior-solve callback reported failure                       */
+
+#define MI_PTR_HOST 0
+#define MI_PTR_DEVICE 1
+
+typedef struct mi_ctx_s *mi_ctx_t; /* device + stream + workspaces (+ RCCL communicator)            */
+typedef struct mi_op_s *mi_op_t;   /* anything usable as `A` (A*x, mul!) or as `M` (M \ r)          */
+typedef struct mi_event_s *mi_event_t;
+
+/* Interior solve callback: sol = A_II[idom]^{-1} rhs on HOST memory, called from the calling
+ * thread only (Julia @cfunction safe). Replaces `IterativeSolvers.cg(A_IIdd, rhs; Pl, reltol)`
+ * inside apply_local_schur / apply_global_schur (EPDD.jl:609-619, 648-650). Return 0 on success. */
+typedef int (*mi_interior_solve_fn)(void *user, int64_t idom, int64_t n, const double *rhs, double *sol);
+
+/* ---------------------------------------------------------------- library / context */
+int mi_version(void);                 /* MAJOR*10000 + MINOR*100 + PATCH */
+const char *mi_last_error(void);
+int mi_device_count(int *count);
+int mi_ctx_create(int device, mi_ctx_t *ctx);
+int mi_ctx_destroy(mi_ctx_t ctx);
+int mi_ctx_set_pointer_mode(mi_ctx_t ctx, int mode);
+int mi_ctx_set_stream(mi_ctx_t ctx, void *hip_stream); /* borrow a hipStream_t; NULL = context's own */
+int mi_ctx_get_stream(mi_ctx_t ctx, void **hip_stream);
+int mi_ctx_synchronize(mi_ctx_t ctx);
+/* Iterations per captured hipGraph launch between host convergence checks (default 8);
+ * 0 disables graphs (eager launches, host check every iteration). Results do not depend on it. */
+int mi_ctx_set_chunk(mi_ctx_t ctx, int iterations_per_graph);
+
+/* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI)
+ * The Γ-interface sum over subdomains — the reference's (dead) `@distributed (+) for idom`,
+ * Fem/EllipticPdePllDomainDecomposition.jl:10-14 — is one ncclAllReduce(sum, fp64, n_Γ).
+ * Rank 0 calls mi_comm_unique_id and ships the 128 bytes to the other ranks by any means
+ * (torch.distributed / MPI / Julia Distributed); every rank then calls mi_ctx_comm_init. */
+#define MI_COMM_ID_BYTES 128
+int mi_comm_unique_id(void *id_out);
+int mi_ctx_comm_init(mi_ctx_t ctx, const void *id, int rank, int n_ranks);
+int mi_ctx_comm_destroy(mi_ctx_t ctx);
+int mi_ctx_allreduce_sum(mi_ctx_t ctx, double *buf, int64_t n); /* in place, follows pointer mode */
+
+/* ---------------------------------------------------------------- operators
+ * mi_csr_create — a symmetric `SparseMatrixCSC{Float64,Int64}` used as `A` in cg/pcg/defcg/defpcg
+ * (`A*x` cg.jl:28,83; `mul!(Ap,A,p)` cg.jl:36,93). Pass colptr/rowval/nzval as
+ * rowptr/colidx/val: for a symmetric matrix the CSC arrays are its CSR arrays.
+ * A non-symmetric CSC matrix passed this way yields `A'*x` (the stdlib's gather form). */
+int mi_csr_create(mi_ctx_t ctx, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
+                  const int64_t *colidx, const double *val, int index_base, mi_op_t *op);
+
+/* mi_diag_create — `M \ r` with M = diag: z = dinv .* r, or the identity when dinv == NULL
+ * (Example01's AMG preconditioner is out of scope; Jacobi / none stand in). */
+int mi_diag_create(mi_ctx_t ctx, int64_t n, const double *dinv, mi_op_t *op);
+
+/* mi_schur_assembled_create — `apply_local_schurs(Sd, ind_Γd_Γ2l, node_Γ_cnt, x)`, EPDD.jl:761-785:
+ * Sx = Σ_d R_d' S_d R_d x with dense local Schur complements.
+ *   Sd[d]          n_gamma_d[d]^2 doubles, column-major (Julia `Array(Sd[d])`)
+ *   gather_idx[d]  n_gamma_d[d] entries: Γ index of Γ_d slot l (the flattened Dict ind_Γd_Γ2l[d]:
+ *                  gather_idx[d][lΓd] = lΓ)
+ * The local slice [dom_begin, dom_end) of the ndom subdomains is applied by this rank; the
+ * per-rank partial sums are combined with an RCCL all-reduce when the context has a communicator
+ * with n_ranks > 1. Pass dom_begin = 0, dom_end = ndom for single-GPU use. Arrays of the other
+ * ranks' subdomains may be NULL. */
+int mi_schur_assembled_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d,
+                              const int64_t *const *gather_idx, const double *const *Sd, int index_base,
+                              int64_t dom_begin, int64_t dom_end, mi_op_t *op);
+
+/* mi_nn_create — `NeumannNeumannSchurPreconditioner(ΠSd, ind_Γd_Γ2l, node_Γ_cnt)` (EPDD.jl:1111-1137)
+ * used through `Πnn \ r` / `ldiv!` = apply_neumann_neumann_schur (EPDD.jl:1361-1403):
+ * z = Σ_d R_d' D_d ΠS_d D_d R_d r, D = diag(1 ./ node_Γ_cnt). ΠSd[d] column-major dense. */
+int mi_nn_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d,
+                 const int64_t *const *gather_idx, const double *const *PiSd, const int64_t *node_gamma_cnt,
+                 int index_base, int64_t dom_begin, int64_t dom_end, mi_op_t *op);
+
+/* mi_schur_matfree_create — `apply_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γd_Γ2l, node_Γ_cnt, x)`,
+ * EPDD.jl:711-747 (per subdomain apply_local_schur, EPDD.jl:639-654):
+ * S_d x_d = A_ΓΓdd x_d − A_IΓdd' (A_IIdd^{-1} (A_IΓdd x_d)). The three sparse products run on the
+ * device; A_IIdd^{-1} is the host callback (BASELINE north_star: interior solve stays on the host).
+ *   A_IΓdd[d]: CSC arrays (colptr n_gamma_d[d]+1, rowval, nzval) of the n_i[d] x n_gamma_d[d] block
+ *   A_ΓΓdd[d]: CSC arrays of the symmetric n_gamma_d[d] x n_gamma_d[d] block */
+int mi_schur_matfree_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d,
+                            const int64_t *n_i, const int64_t *const *gather_idx,
+                            const int64_t *const *ig_colptr, const int64_t *const *ig_rowval,
+                            const double *const *ig_nzval, const int64_t *const *gg_colptr,
+                            const int64_t *const *gg_rowval, const double *const *gg_nzval,
+                            mi_interior_solve_fn solve, void *user, int index_base,
+                            int64_t dom_begin, int64_t dom_end, mi_op_t *op);
+
+/* mi_schur_global_create — `apply_global_schur(A_IId, A_IΓd, A_ΓΓ, x)`, EPDD.jl:596-625:
+ * Sx = A_ΓΓ x − Σ_d A_IΓd' (A_IId^{-1} (A_IΓd x)), Γ-global column indices (no gather maps).
+ *   A_IΓd[d]: CSC arrays of the n_i[d] x n_gamma block;  A_ΓΓ: CSC arrays, symmetric. */
+int mi_schur_global_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_i,
+                           const int64_t *const *ig_colptr, const int64_t *const *ig_rowval,
+                           const double *const *ig_nzval, const int64_t *gg_colptr,
+                           const int64_t *gg_rowval, const double *gg_nzval,
+                           mi_interior_solve_fn solve, void *user, int index_base, mi_op_t *op);
+
+int mi_op_size(mi_op_t op, int64_t *n);
+/* y = A*x (operator) or y = M \ x (preconditioner); x and y must not alias. */
+int mi_op_apply(mi_op_t op, const double *x, double *y);
+/* Algorithmic bytes of one apply (SURVEY.md §8d formulas) and of its dominant kernel alone. */
+int mi_op_bytes(mi_op_t op, int64_t *bytes_apply, int64_t *bytes_dominant_kernel);
+/* Diagnostic: launch only the dominant kernel of the apply `reps` times (x as in mi_op_apply). */
+int mi_op_apply_dominant(mi_op_t op, const double *x, int reps);
+int mi_op_destroy(mi_op_t op);
+
+/* ---------------------------------------------------------------- BLAS-1 on the device
+ * `dot`, `norm2`, `axpy!`, `axpby!` as imported at RecyclingKrylovSolvers.jl:3 (level-1 drop-ins). */
+int mi_dot(mi_ctx_t ctx, int64_t n, const double *x, const double *y, double *result);
+int mi_norm2(mi_ctx_t ctx, int64_t n, const double *x, double *result);
+int mi_axpy(mi_ctx_t ctx, int64_t n, double a, const double *x, double *y);            /* y += a x     */
+int mi_axpby(mi_ctx_t ctx, int64_t n, double a, const double *x, double b, double *y); /* y = a x + b y */
+
+/* ---------------------------------------------------------------- solvers (whole loop on the device)
+ * Reference signatures (RecyclingKrylovSolvers/cg.jl:14-18, 67-72; defcg.jl:24-29, 242-248):
+ *     cg(A,b,x;maxit=0)  pcg(A,b,x,M;maxit=0)  defcg(A,b,x,W;maxit=0)  defpcg(A,b,x,W,M;maxit=0)
+ *     -> (x, it, res_norm[1:it])
+ * x is read as the initial guess and overwritten with the solution (the reference mutates x).
+ * maxit == 0 means n (cg.jl:25). eps is the module constant 1e-7 (RecyclingKrylovSolvers.jl:21)
+ * made explicit; pass eps <= 0 for that default. Stop rule (cg.jl:34, 91): iterate while
+ * it < maxit && res_norm[it] > eps*norm2(b), with res_norm[it] = sqrt(r'r) of the recurrence
+ * residual; `it` counts from 1. res_norm receives it entries (capacity res_cap >= it required,
+ * else MI_ERR_RES_CAPACITY after the solve completed). W is n x nvec, column-major. */
+int mi_cg(mi_op_t A, const double *b, double *x, int64_t maxit, double eps, double *res_norm,
+          int64_t res_cap, int64_t *it);
+int mi_pcg(mi_op_t A, mi_op_t M, const double *b, double *x, int64_t maxit, double eps,
+           double *res_norm, int64_t res_cap, int64_t *it);
+int mi_defcg(mi_op_t A, const double *b, double *x, const double *W, int64_t nvec, int64_t maxit,
+             double eps, double *res_norm, int64_t res_cap, int64_t *it);
+int mi_defpcg(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec,
+              int64_t maxit, double eps, double *res_norm, int64_t res_cap, int64_t *it);
+
+/* ---------------------------------------------------------------- timing on the context's stream */
+int mi_event_create(mi_event_t *ev);
+int mi_event_record(mi_ctx_t ctx, mi_event_t ev);
+int mi_event_elapsed_ms(mi_event_t start, mi_event_t stop, double *ms); /* synchronises on stop */
+int mi_event_destroy(mi_event_t ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355SCHUR_H */

@@ -1,0 +1,471 @@
+"""Host-side mirror of the reference's operator / preconditioner / solver interface for the
+Schur-PCG hot path, on top of the C ABI (include/mi355schur.h). Same names, argument order and
+return values as the Julia functions; citations are relative to /root/reference
+("EPDD.jl" = Fem/EllipticPdeDomainDecomposition.jl).
+
+    cg(A, b, x; maxit=0)            -> (x, it, res_norm[1:it])     RecyclingKrylovSolvers/cg.jl:14
+    pcg(A, b, x, M; maxit=0)                                        cg.jl:67
+    defcg(A, b, x, W; maxit=0)                                      defcg.jl:24
+    defpcg(A, b, x, W, M; maxit=0)                                  defcg.jl:242
+    apply_local_schurs(S, x)  /  S * x                              EPDD.jl:711-785
+    apply_global_schur(S, x)                                        EPDD.jl:596-625
+    NeumannNeumannSchurPreconditioner(ΠSd, ind_Γd_Γ2l, node_Γ_cnt)  EPDD.jl:1111-1137
+    apply_neumann_neumann_schur(Πnn, r)  /  Πnn.ldiv(r)             EPDD.jl:1361-1403
+
+Vectors may be numpy arrays (host pointers; copied through the boundary like Julia arrays) or
+torch CUDA tensors (device pointers, zero copy). Indices are 0-based (`index_base=0`); a Julia
+caller passes `index_base=1` through the shim in julia/MI355Schur.jl.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import (BoundsError, MiError, SingularException, check, f64p, f64pp, i64, i64p, i64pp, vp)  # noqa: F401
+
+EPS = 1e-7  # RecyclingKrylovSolvers.jl:21 `const eps = 1e-7`
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _ptrs(arrs, elem_ptr_type):
+    """C array of pointers; None entries become NULL (other ranks' subdomains)."""
+    out = (elem_ptr_type * len(arrs))()
+    for k, a in enumerate(arrs):
+        out[k] = a.ctypes.data_as(elem_ptr_type) if a is not None else None
+    return out
+
+
+class Context:
+    """One GPU + one HIP stream (+ an optional RCCL communicator). `mi_ctx_t`."""
+
+    def __init__(self, device: int = 0):
+        L = _lib.load()
+        h = vp()
+        check(L.mi_ctx_create(C.c_int(device), C.byref(h)))
+        self._h, self._L, self.device = h, L, device
+        self.rank, self.n_ranks = 0, 1
+
+    # -- pointer mode follows the argument type of each call
+    def _mode_for(self, *vecs) -> int:
+        dev = [v for v in vecs if v is not None and _is_torch(v)]
+        if dev and len(dev) != len([v for v in vecs if v is not None]):
+            raise TypeError("mix of torch tensors and numpy arrays in one call")
+        mode = _lib.MI_PTR_DEVICE if dev else _lib.MI_PTR_HOST
+        check(self._L.mi_ctx_set_pointer_mode(self._h, mode))
+        return mode
+
+    @staticmethod
+    def _ptr(v, n: Optional[int] = None, writable: bool = False):
+        """(keepalive, void*) of a contiguous fp64 vector."""
+        if v is None:
+            return None, None
+        if _is_torch(v):
+            import torch
+            if v.dtype != torch.float64 or not v.is_cuda or not v.is_contiguous():
+                raise TypeError("device vectors must be contiguous float64 CUDA tensors")
+            if n is not None and v.numel() != n:
+                raise ValueError(f"expected {n} entries, got {v.numel()}")
+            return v, vp(v.data_ptr())
+        a = v if (isinstance(v, np.ndarray) and v.dtype == np.float64 and v.flags.c_contiguous
+                  and (v.flags.writeable or not writable)) else _f64(v)
+        if n is not None and a.size != n:
+            raise ValueError(f"expected {n} entries, got {a.size}")
+        return a, vp(a.ctypes.data)
+
+    def set_chunk(self, iterations_per_graph: int) -> None:
+        check(self._L.mi_ctx_set_chunk(self._h, C.c_int(iterations_per_graph)))
+
+    def use_torch_stream(self) -> None:
+        """Launch on torch's current stream (so torch.cuda.Event sees our kernels)."""
+        import torch
+        check(self._L.mi_ctx_set_stream(self._h, vp(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def synchronize(self) -> None:
+        check(self._L.mi_ctx_synchronize(self._h))
+
+    # -- RCCL
+    def unique_id(self) -> bytes:
+        buf = C.create_string_buffer(_lib.MI_COMM_ID_BYTES)
+        check(self._L.mi_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid: bytes, rank: int, n_ranks: int) -> None:
+        buf = C.create_string_buffer(uid, _lib.MI_COMM_ID_BYTES)
+        check(self._L.mi_ctx_comm_init(self._h, buf, C.c_int(rank), C.c_int(n_ranks)))
+        self.rank, self.n_ranks = rank, n_ranks
+
+    def allreduce_sum(self, v):
+        self._mode_for(v)
+        keep, p = self._ptr(v, writable=True)
+        n = keep.numel() if _is_torch(keep) else keep.size
+        check(self._L.mi_ctx_allreduce_sum(self._h, p, i64(n)))
+        return keep
+
+    # -- BLAS-1 (RecyclingKrylovSolvers.jl:3)
+    def dot(self, x, y) -> float:
+        self._mode_for(x, y)
+        kx, px = self._ptr(x)
+        n = kx.numel() if _is_torch(kx) else kx.size
+        ky, py = self._ptr(y, n)
+        out = C.c_double()
+        check(self._L.mi_dot(self._h, i64(n), px, py, C.byref(out)))
+        return out.value
+
+    def norm2(self, x) -> float:
+        self._mode_for(x)
+        kx, px = self._ptr(x)
+        n = kx.numel() if _is_torch(kx) else kx.size
+        out = C.c_double()
+        check(self._L.mi_norm2(self._h, i64(n), px, C.byref(out)))
+        return out.value
+
+    def axpy(self, a: float, x, y):
+        """axpy!(a, x, y): y += a*x, returns y (numpy input: a new array unless y is writable fp64)."""
+        self._mode_for(x, y)
+        ky, py = self._ptr(y, writable=True)
+        n = ky.numel() if _is_torch(ky) else ky.size
+        kx, px = self._ptr(x, n)
+        check(self._L.mi_axpy(self._h, i64(n), C.c_double(a), px, py))
+        return ky
+
+    def axpby(self, a: float, x, b: float, y):
+        """axpby!(a, x, b, y): y = a*x + b*y."""
+        self._mode_for(x, y)
+        ky, py = self._ptr(y, writable=True)
+        n = ky.numel() if _is_torch(ky) else ky.size
+        kx, px = self._ptr(x, n)
+        check(self._L.mi_axpby(self._h, i64(n), C.c_double(a), px, C.c_double(b), py))
+        return ky
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.mi_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._h = vp()
+        check(ctx._L.mi_event_create(C.byref(self._h)))
+
+    def record(self) -> "Event":
+        check(self.ctx._L.mi_event_record(self.ctx._h, self._h))
+        return self
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        out = C.c_double()
+        check(self.ctx._L.mi_event_elapsed_ms(self._h, stop._h, C.byref(out)))
+        return out.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.ctx._L.mi_event_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Operator:
+    """`mi_op_t`: anything the solvers use through `A*x` / `mul!` or `M \\ r`."""
+
+    def __init__(self, ctx: Context, handle, keep=()):
+        self.ctx, self._h, self._keep = ctx, handle, keep
+        n = i64()
+        check(ctx._L.mi_op_size(handle, C.byref(n)))
+        self.n = self.N = int(n.value)   # `.N` as LinearMaps.FunctionMap exposes it (Example07:273)
+
+    def apply(self, x, out=None):
+        self.ctx._mode_for(x, out)
+        kx, px = self.ctx._ptr(x, self.n)
+        if out is None:
+            if _is_torch(kx):
+                import torch
+                out = torch.empty_like(kx)
+            else:
+                out = np.empty(self.n)
+        ko, po = self.ctx._ptr(out, self.n, writable=True)
+        check(self.ctx._L.mi_op_apply(self._h, px, po))
+        return ko
+
+    __call__ = apply
+    __mul__ = apply          # A * x
+    ldiv = apply             # M \ r  (`\` has no Python spelling)
+
+    def bytes(self):
+        a, d = i64(), i64()
+        check(self.ctx._L.mi_op_bytes(self._h, C.byref(a), C.byref(d)))
+        return int(a.value), int(d.value)
+
+    def apply_dominant(self, x, reps: int = 1) -> None:
+        self.ctx._mode_for(x)
+        kx, px = self.ctx._ptr(x, self.n)
+        check(self.ctx._L.mi_op_apply_dominant(self._h, px, C.c_int(reps)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self.ctx._L.mi_op_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ operator constructors
+def SparseMatrixCSC(ctx: Context, A, index_base: int = 0) -> Operator:
+    """A symmetric `SparseMatrixCSC{Float64,Int}` as the solvers' `A` (cg.jl:14-15).
+    `A` is a scipy sparse matrix or a (colptr, rowval, nzval, n) tuple."""
+    if isinstance(A, tuple):
+        ptr, idx, val, n = A
+        ptr, idx, val = _i64(ptr), _i64(idx), _f64(val)
+    else:
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        n = A.shape[0]
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("square matrix expected")
+        ptr, idx, val = _i64(A.indptr), _i64(A.indices), _f64(A.data)
+    h = vp()
+    check(ctx._L.mi_csr_create(ctx._h, i64(n), i64(n), ptr.ctypes.data_as(i64p), idx.ctypes.data_as(i64p),
+                               val.ctypes.data_as(f64p), C.c_int(index_base), C.byref(h)))
+    return Operator(ctx, h)
+
+
+def IdentityPreconditioner(ctx: Context, n: int) -> Operator:
+    h = vp()
+    check(ctx._L.mi_diag_create(ctx._h, i64(n), None, C.byref(h)))
+    return Operator(ctx, h)
+
+
+def JacobiPreconditioner(ctx: Context, diag) -> Operator:
+    """z = r ./ diag(A) — stands in for Example01's AMG preconditioner (out of scope)."""
+    dinv = _f64(1.0 / np.asarray(diag, dtype=np.float64))
+    h = vp()
+    check(ctx._L.mi_diag_create(ctx._h, i64(dinv.size), dinv.ctypes.data_as(f64p), C.byref(h)))
+    return Operator(ctx, h)
+
+
+def _dom_slice(ctx: Context, ndom: int, dom_slice):
+    if dom_slice is None:
+        return shard_domains(ndom, ctx.rank, ctx.n_ranks)
+    return int(dom_slice[0]), int(dom_slice[1])
+
+
+def shard_domains(ndom: int, rank: int, n_ranks: int):
+    """Contiguous block of subdomains owned by `rank` (8 subdomains: 8/4/2/1 per GPU at 1/2/4/8 GPUs)."""
+    lo = ndom * rank // n_ranks
+    hi = ndom * (rank + 1) // n_ranks
+    return lo, hi
+
+
+def _blocks(blocks, lo, hi):
+    out = []
+    for d, b in enumerate(blocks):
+        out.append(np.asfortranarray(np.asarray(b, dtype=np.float64)) if (lo <= d < hi and b is not None) else None)
+    return out
+
+
+class LocalSchurs(Operator):
+    """Assembled Schur operator: `x -> apply_local_schurs(Sd, ind_Γd_Γ2l, node_Γ_cnt, x)` (EPDD.jl:761-785),
+    i.e. the closure Example03:131-135 wraps in a LinearMap."""
+
+    def __init__(self, ctx: Context, Sd: Sequence, ind_Γd_Γ2l: Sequence, node_Γ_cnt, index_base: int = 0,
+                 dom_slice=None):
+        ndom = len(Sd)
+        n_Γ = len(node_Γ_cnt)
+        lo, hi = _dom_slice(ctx, ndom, dom_slice)
+        g = [_i64(a) for a in ind_Γd_Γ2l]
+        nd = _i64([a.size for a in g])
+        S = _blocks(Sd, lo, hi)
+        for d in range(lo, hi):
+            if S[d].shape != (nd[d], nd[d]):
+                raise ValueError(f"Sd[{d}] has shape {S[d].shape}, expected {(nd[d], nd[d])}")
+        h = vp()
+        check(ctx._L.mi_schur_assembled_create(ctx._h, i64(ndom), i64(n_Γ), nd.ctypes.data_as(i64p), _ptrs(g, i64p),
+                                               _ptrs(S, f64p), C.c_int(index_base), i64(lo), i64(hi), C.byref(h)))
+        super().__init__(ctx, h)
+        self.dom_slice = (lo, hi)
+
+
+class NeumannNeumannSchurPreconditioner(Operator):
+    """`NeumannNeumannSchurPreconditioner(ΠSd, ind_Γd_Γ2l, node_Γ_cnt)` (EPDD.jl:1111-1137); used by the
+    solvers through `Πnn \\ r` (EPDD.jl:1389-1392) = `apply_neumann_neumann_schur` (EPDD.jl:1361-1386)."""
+
+    def __init__(self, ctx: Context, ΠSd: Sequence, ind_Γd_Γ2l: Sequence, node_Γ_cnt, index_base: int = 0,
+                 dom_slice=None):
+        ndom = len(ΠSd)
+        cnt = _i64(node_Γ_cnt)
+        lo, hi = _dom_slice(ctx, ndom, dom_slice)
+        g = [_i64(a) for a in ind_Γd_Γ2l]
+        nd = _i64([a.size for a in g])
+        P = _blocks(ΠSd, lo, hi)
+        h = vp()
+        check(ctx._L.mi_nn_create(ctx._h, i64(ndom), i64(cnt.size), nd.ctypes.data_as(i64p), _ptrs(g, i64p),
+                                  _ptrs(P, f64p), cnt.ctypes.data_as(i64p), C.c_int(index_base), i64(lo), i64(hi),
+                                  C.byref(h)))
+        super().__init__(ctx, h)
+        self.dom_slice = (lo, hi)
+
+
+def _wrap_interior(solvers: Sequence[Callable]):
+    """`solvers[d](rhs) -> A_II[d]^{-1} rhs` on the host, as the C callback (EPDD.jl:648-650)."""
+    def cb(_user, idom, n, rhs, sol):
+        try:
+            r = np.ctypeslib.as_array(rhs, shape=(n,))
+            s = np.ctypeslib.as_array(sol, shape=(n,))
+            s[:] = solvers[idom](r.copy())
+            return 0
+        except Exception:  # never let an exception cross the C frame
+            return 1
+    return _lib.INTERIOR_SOLVE_FN(cb)
+
+
+def _csc_parts(mats, lo, hi):
+    ptr, idx, val = [], [], []
+    for d, m in enumerate(mats):
+        if lo <= d < hi:
+            m = sp.csc_matrix(m)
+            m.sort_indices()
+            ptr.append(_i64(m.indptr)); idx.append(_i64(m.indices)); val.append(_f64(m.data))
+        else:
+            ptr.append(None); idx.append(None); val.append(None)
+    return ptr, idx, val
+
+
+class MatrixFreeLocalSchurs(Operator):
+    """`x -> apply_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γd_Γ2l, node_Γ_cnt, x; preconds)` (EPDD.jl:711-747),
+    the closure of Example03:143-150. Sparse products on the device, `A_IIdd^{-1}` through `interior_solvers`."""
+
+    def __init__(self, ctx: Context, A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γd_Γ2l, node_Γ_cnt, interior_solvers,
+                 dom_slice=None):
+        ndom = len(A_IΓdd)
+        n_Γ = len(node_Γ_cnt)
+        lo, hi = _dom_slice(ctx, ndom, dom_slice)
+        g = [_i64(a) for a in ind_Γd_Γ2l]
+        nd = _i64([a.size for a in g])
+        ni = _i64([A.shape[0] for A in A_IIdd])
+        igp, igi, igv = _csc_parts(A_IΓdd, lo, hi)
+        ggp, ggi, ggv = _csc_parts(A_ΓΓdd, lo, hi)
+        cb = _wrap_interior(interior_solvers)
+        h = vp()
+        check(ctx._L.mi_schur_matfree_create(
+            ctx._h, i64(ndom), i64(n_Γ), nd.ctypes.data_as(i64p), ni.ctypes.data_as(i64p), _ptrs(g, i64p),
+            _ptrs(igp, i64p), _ptrs(igi, i64p), _ptrs(igv, f64p), _ptrs(ggp, i64p), _ptrs(ggi, i64p), _ptrs(ggv, f64p),
+            cb, None, C.c_int(0), i64(lo), i64(hi), C.byref(h)))
+        super().__init__(ctx, h, keep=(cb, interior_solvers))
+
+
+class GlobalSchur(Operator):
+    """`x -> apply_global_schur(A_IId, A_IΓd, A_ΓΓ, x; preconds)` (EPDD.jl:596-625), the closure of Example03:101."""
+
+    def __init__(self, ctx: Context, A_IId, A_IΓd, A_ΓΓ, interior_solvers):
+        ndom = len(A_IΓd)
+        n_Γ = A_ΓΓ.shape[0]
+        ni = _i64([A.shape[0] for A in A_IId])
+        igp, igi, igv = _csc_parts(A_IΓd, 0, ndom)
+        (ggp,), (ggi,), (ggv,) = _csc_parts([A_ΓΓ], 0, 1)
+        cb = _wrap_interior(interior_solvers)
+        h = vp()
+        check(ctx._L.mi_schur_global_create(
+            ctx._h, i64(ndom), i64(n_Γ), ni.ctypes.data_as(i64p), _ptrs(igp, i64p), _ptrs(igi, i64p), _ptrs(igv, f64p),
+            ggp.ctypes.data_as(i64p), ggi.ctypes.data_as(i64p), ggv.ctypes.data_as(f64p), cb, None, C.c_int(0), C.byref(h)))
+        super().__init__(ctx, h, keep=(cb, interior_solvers))
+
+
+# reference-named free functions
+def apply_local_schurs(S: Operator, x):
+    return S.apply(x)
+
+
+def apply_global_schur(S: GlobalSchur, x):
+    return S.apply(x)
+
+
+def apply_neumann_neumann_schur(Πnn: NeumannNeumannSchurPreconditioner, r):
+    return Πnn.apply(r)
+
+
+# ------------------------------------------------------------------ solvers
+def _solve(kind: str, A: Operator, M: Optional[Operator], b, x, W, maxit: int, eps: float):
+    ctx = A.ctx
+    n = A.n
+    ctx._mode_for(b, x, W)
+    kb, pb = ctx._ptr(b, n)
+    if _is_torch(x):
+        kx, px = ctx._ptr(x, n, writable=True)       # mutated in place like the reference's x
+    else:
+        kx = np.array(x, dtype=np.float64, copy=True)
+        if kx.size != n:
+            raise ValueError(f"expected {n} entries, got {kx.size}")
+        px = vp(kx.ctypes.data)
+    cap = int(min(maxit if maxit else n, n)) + 1
+    res = np.empty(cap)
+    it = i64()
+    L = ctx._L
+    tail = (i64(maxit), C.c_double(eps), res.ctypes.data_as(f64p), i64(cap), C.byref(it))
+    if W is not None:
+        if _is_torch(W):
+            if W.dim() != 2 or W.shape[0] != n or W.stride(0) != 1:
+                raise TypeError("W must be an n x nvec column-major tensor (e.g. torch.empty(nvec, n).T)")
+            nvec, kW, pW = W.shape[1], W, vp(W.data_ptr())
+        else:
+            kW = np.asfortranarray(W, dtype=np.float64)
+            if kW.ndim != 2 or kW.shape[0] != n:
+                raise ValueError("W must be n x nvec")
+            nvec, pW = kW.shape[1], vp(kW.ctypes.data)
+    if kind == "cg":
+        rc = L.mi_cg(A._h, pb, px, *tail)
+    elif kind == "pcg":
+        rc = L.mi_pcg(A._h, M._h, pb, px, *tail)
+    elif kind == "defcg":
+        rc = L.mi_defcg(A._h, pb, px, pW, i64(nvec), *tail)
+    else:
+        rc = L.mi_defpcg(A._h, M._h, pb, px, pW, i64(nvec), *tail)
+    check(rc)
+    k = int(it.value)
+    return kx, k, res[:k].copy()
+
+
+def cg(A: Operator, b, x, maxit: int = 0, eps: float = EPS):
+    """cg(A, b, x; maxit=0) (cg.jl:14-50)."""
+    return _solve("cg", A, None, b, x, None, maxit, eps)
+
+
+def pcg(A: Operator, b, x, M: Operator, maxit: int = 0, eps: float = EPS):
+    """pcg(A, b, x, M; maxit=0) (cg.jl:67-109)."""
+    return _solve("pcg", A, M, b, x, None, maxit, eps)
+
+
+def defcg(A: Operator, b, x, W, maxit: int = 0, eps: float = EPS):
+    """defcg(A, b, x, W; maxit=0) (defcg.jl:24-83)."""
+    return _solve("defcg", A, None, b, x, W, maxit, eps)
+
+
+def defpcg(A: Operator, b, x, W, M: Operator, maxit: int = 0, eps: float = EPS):
+    """defpcg(A, b, x, W, M; maxit=0) (defcg.jl:242-308) — note the reference's (A,b,x,W,M) order."""
+    return _solve("defpcg", A, M, b, x, W, maxit, eps)

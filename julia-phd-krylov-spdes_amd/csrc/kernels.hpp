@@ -1,0 +1,424 @@
+// Device kernels of libmi355schur (gfx950 / CDNA4, wave64). All arithmetic fp64, built with
+// -ffp-contract=off so that element-wise updates and the CSR row sums reproduce the
+// reference's mul-then-add sequence bit for bit; only tree reductions reorder sums.
+//
+// Every kernel that runs inside the Krylov loop takes `const int *done`: once the stop rule
+// (cg.jl:34,91) has fired, the remaining launches of a captured iteration chunk return at once.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mi {
+
+constexpr int NT = 256;        // threads per workgroup for all streaming kernels (4 waves)
+constexpr int MAX_PARTS = 512; // max workgroups of a vector kernel = max partial sums per dot
+
+// Scalars of one Krylov solve, resident in HBM (read by every workgroup, written by one).
+struct SolverState {
+  double rTr, rTz;            // current r'r and r'z
+  double rTr_prev, rTz_prev;  // values before this iteration's update (for beta = (1/old)*new)
+  double d, alpha, beta;      // diagnostics (each workgroup recomputes them from the partials)
+  double tol, bnorm;
+  long long it, maxit, res_cap;
+  int done;
+  int overflow;               // res_norm capacity hit (BoundsError in the reference)
+};
+
+// ------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // lane 0 holds the sum
+}
+// Deterministic workgroup sum, result broadcast to all NT threads. `sm` has NT/64 + 1 doubles.
+__device__ __forceinline__ double block_sum(double v, double *sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < NT / 64; ++i) t += sm[i];
+    sm[NT / 64] = t;
+  }
+  __syncthreads();
+  const double t = sm[NT / 64];
+  __syncthreads();
+  return t;
+}
+// Sum of `g` per-workgroup partials, in a fixed order, identical in every workgroup.
+__device__ __forceinline__ double sum_partials(const double *part, int g, double *sm) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < g; i += NT) v += part[i];
+  return block_sum(v, sm);
+}
+
+// ------------------------------------------------------------------ BLAS-1 building blocks
+__global__ __launch_bounds__(NT) void k_dot_partial(int n, const double *__restrict__ x,
+                                                    const double *__restrict__ y, double *__restrict__ part,
+                                                    const int *done) {
+  if (done && *done) return;
+  __shared__ double sm[NT / 64 + 1];
+  double s = 0.0;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) s += x[i] * y[i];
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// out[0] = sum(part[0..g)) (or its square root)
+__global__ __launch_bounds__(NT) void k_finish_sum(const double *part, int g, double *out, int take_sqrt) {
+  __shared__ double sm[NT / 64 + 1];
+  double s = sum_partials(part, g, sm);
+  if (threadIdx.x == 0) out[0] = take_sqrt ? sqrt(s) : s;
+}
+__global__ __launch_bounds__(NT) void k_axpy(int n, double a, const double *__restrict__ x, double *__restrict__ y) {
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) y[i] = y[i] + a * x[i];
+}
+__global__ __launch_bounds__(NT) void k_axpby(int n, double a, const double *__restrict__ x, double b,
+                                              double *__restrict__ y) {
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) y[i] = a * x[i] + b * y[i];
+}
+// z = dinv .* r (Jacobi) or z = r (identity)
+__global__ __launch_bounds__(NT) void k_diag_apply(int n, const double *__restrict__ dinv,
+                                                   const double *__restrict__ r, double *__restrict__ z,
+                                                   const int *done) {
+  if (done && *done) return;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) z[i] = dinv ? dinv[i] * r[i] : r[i];
+}
+
+// ------------------------------------------------------------------ CSR SpMV ("CSR-stream")
+// One workgroup owns a block of consecutive rows holding <= SPMV_TILE non-zeros. Phase 1 streams
+// the block's column indices and values with coalesced loads, gathers x and parks the products in
+// LDS; phase 2 gives each row to one thread, which adds its products left to right — the order
+// of the reference's CSC scatter SpMV for a symmetric matrix (stdlib SparseArrays `A*x`,
+// `y[rowval[k]] += nzval[k]*x[j]`, j ascending), so y is bit-identical to it.
+// Row blocks are dealt to XCDs in contiguous ranges (blockIdx % 8 selects the range) so that each
+// XCD's L2 caches one slice of x instead of all of it.
+constexpr int SPMV_TILE = 2048;
+
+template <int MODE>  // 0: y = A x      1: y = yin - A x
+__global__ __launch_bounds__(NT) void k_spmv_csr(int nblocks, const int *__restrict__ rb,
+                                                 const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                 const double *__restrict__ val, const double *__restrict__ x,
+                                                 const double *yin, double *y, const int *done) {
+  if (done && *done) return;
+  __shared__ double prod[SPMV_TILE];
+  const int per = (nblocks + 7) >> 3;
+  const int b = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (b >= nblocks) return;
+  const int r0 = rb[b], r1 = rb[b + 1];
+  const int k0 = rowptr[r0], k1 = rowptr[r1];
+  const int nnz = k1 - k0;
+  if (nnz <= SPMV_TILE) {
+    for (int k = threadIdx.x; k < nnz; k += NT) prod[k] = val[k0 + k] * x[col[k0 + k]];
+    __syncthreads();
+    for (int r = r0 + threadIdx.x; r < r1; r += NT) {
+      const int a = rowptr[r] - k0, e = rowptr[r + 1] - k0;
+      double s = 0.0;
+      for (int k = a; k < e; ++k) s += prod[k];
+      y[r] = MODE ? yin[r] - s : s;
+    }
+  } else {
+    // a single row longer than the tile (never the case for P1-FEM blocks): tile by tile,
+    // thread 0 keeps the running left-to-right sum.
+    double s = 0.0;
+    for (int t0 = 0; t0 < nnz; t0 += SPMV_TILE) {
+      const int m = min(SPMV_TILE, nnz - t0);
+      for (int k = threadIdx.x; k < m; k += NT) prod[k] = val[k0 + t0 + k] * x[col[k0 + t0 + k]];
+      __syncthreads();
+      if (threadIdx.x == 0)
+        for (int k = 0; k < m; ++k) s += prod[k];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) y[r0] = MODE ? yin[r0] - s : s;
+  }
+}
+
+// ------------------------------------------------------------------ batched dense GEMV with fused gather
+// y_loc[d] = M_d * (D_d R_d x)  [* D_d], for all subdomains d of this rank in one launch.
+//   S-apply  (SCALE=false): M_d = S_d,  EPDD.jl:775-778  (gather, `Sd[idom]*xd`)
+//   NN-apply (SCALE=true) : M_d = ΠS_d, EPDD.jl:1373-1381 (gather r/cnt, `ΠSd[idom]*rd`, result /cnt)
+// Layout: every M_d is stored row-major with its leading dimension padded to a multiple of 16
+// doubles (128 B), so each row is a contiguous, line-aligned stream. A workgroup owns RPW rows per
+// wave (4*RPW rows); x_d is gathered once per workgroup into LDS (padded with zeros); each lane
+// streams 16 B per row per step (1 KiB per wave-instruction), multiplies against the LDS copy of
+// x_d and the row sum is finished with a wave shuffle tree. The scatter-add over subdomains is a
+// separate deterministic pass (k_assemble) in the reference's idom-ascending order.
+struct DenseMeta {
+  const double *M;           // all blocks of this rank, row-major, padded
+  const long long *mat_off;  // [ndl] element offset of block d
+  const int *n;              // [ndl] n_Γd
+  const int *ld;             // [ndl] padded leading dimension
+  const int *loc_off;        // [ndl] offset of block d in the concatenated local vectors
+  const int *gidx;           // [nloc] Γ index of every local slot
+  const double *cnt;         // [nloc] node_Γ_cnt as double (NN only)
+  const int *tile_dom;       // [ntiles]
+  const int *tile_row0;      // [ntiles]
+};
+constexpr int GEMV_PANEL = 2048;  // doubles of x_d staged per pass (16 KiB LDS)
+
+template <int RPW, bool SCALE>
+__global__ __launch_bounds__(NT) void k_gemv_batched(DenseMeta m, const double *__restrict__ x,
+                                                     double *__restrict__ yloc, const int *done) {
+  if (done && *done) return;
+  __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
+  const int d = m.tile_dom[blockIdx.x];
+  const int n = m.n[d], ld = m.ld[d], off = m.loc_off[d];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row_base = m.tile_row0[blockIdx.x] + w * RPW;
+  const double *Md = m.M + m.mat_off[d];
+  const double *rowp[RPW];
+  double acc[RPW];
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int r = min(row_base + k, n - 1);  // clamp: tail rows re-read a valid row, result dropped
+    rowp[k] = Md + (long long)r * ld;
+    acc[k] = 0.0;
+  }
+  for (int c0 = 0; c0 < ld; c0 += GEMV_PANEL) {
+    const int pw = min(GEMV_PANEL, ld - c0);  // multiple of 16
+    if (c0) __syncthreads();
+    for (int l = threadIdx.x; l < pw; l += NT) {
+      const int j = c0 + l;
+      double v = 0.0;
+      if (j < n) {
+        v = x[m.gidx[off + j]];
+        if (SCALE) v = v / m.cnt[off + j];
+      }
+      xs[l] = v;
+    }
+    __syncthreads();
+    for (int cb = 0; cb < pw; cb += 512) {
+      double2 mv[RPW][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = cb + u * 128 + lane * 2;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k)
+          mv[k][u] = (c < pw) ? *reinterpret_cast<const double2 *>(rowp[k] + c0 + c) : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = cb + u * 128 + lane * 2;
+        const double2 xv = (c < pw) ? *reinterpret_cast<const double2 *>(&xs[c]) : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+          acc[k] += mv[k][u].x * xv.x;
+          acc[k] += mv[k][u].y * xv.y;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const double s = wave_sum(acc[k]);
+    const int r = row_base + k;
+    if (lane == 0 && r < n) yloc[off + r] = SCALE ? s / m.cnt[off + r] : s;
+  }
+}
+
+// y[i] = sum of the local contributions to Γ node i, in ascending subdomain order
+// (`Sx[lΓ] += Sdxd[lΓd]` for idom = 1..ndom, EPDD.jl:779-781 / 1379-1381).
+__global__ __launch_bounds__(NT) void k_assemble(int n, const int *__restrict__ aptr, const int *__restrict__ apos,
+                                                 const double *__restrict__ yloc, double *__restrict__ y,
+                                                 const int *done) {
+  if (done && *done) return;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    double s = 0.0;
+    for (int k = aptr[i]; k < aptr[i + 1]; ++k) s += yloc[apos[k]];
+    y[i] = s;
+  }
+}
+// xcat[slot] = x[gidx[slot]] for every local slot (matrix-free path: xd[lΓd] = x[lΓ], EPDD.jl:728-730)
+__global__ __launch_bounds__(NT) void k_gather(int nloc, const int *__restrict__ gidx, const double *__restrict__ x,
+                                               double *__restrict__ xcat) {
+  for (int i = blockIdx.x * NT + threadIdx.x; i < nloc; i += gridDim.x * NT) xcat[i] = x[gidx[i]];
+}
+
+// ------------------------------------------------------------------ Krylov loop kernels
+// Set-up:  r = b - Ap; partial r'r and b'b.
+__global__ __launch_bounds__(NT) void k_residual(int n, const double *__restrict__ b, const double *__restrict__ Ap,
+                                                 double *__restrict__ r, double *__restrict__ part_rr,
+                                                 double *__restrict__ part_bb) {
+  __shared__ double sm[NT / 64 + 1];
+  double srr = 0.0, sbb = 0.0;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    const double bi = b[i];
+    const double ri = bi - Ap[i];
+    r[i] = ri;
+    srr += ri * ri;
+    sbb += bi * bi;
+  }
+  srr = block_sum(srr, sm);
+  sbb = block_sum(sbb, sm);
+  if (threadIdx.x == 0) {
+    part_rr[blockIdx.x] = srr;
+    if (part_bb) part_bb[blockIdx.x] = sbb;
+  }
+}
+// Set-up: it = 1; res_norm[1] = sqrt(r'r); tol = eps*norm2(b) (cg.jl:26-32 / 81-89).
+__global__ __launch_bounds__(NT) void k_init_state(SolverState *st, const double *part_rr, const double *part_bb,
+                                                   const double *part_rz, int g, double eps, long long maxit,
+                                                   long long res_cap, double *res_norm) {
+  __shared__ double sm[NT / 64 + 1];
+  const double rr = sum_partials(part_rr, g, sm);
+  const double bb = sum_partials(part_bb, g, sm);
+  const double rz = part_rz ? sum_partials(part_rz, g, sm) : rr;
+  if (threadIdx.x == 0) {
+    st->rTr = rr; st->rTz = rz; st->rTr_prev = rr; st->rTz_prev = rz;
+    st->bnorm = sqrt(bb);
+    st->tol = eps * st->bnorm;
+    st->it = 1; st->maxit = maxit; st->res_cap = res_cap;
+    st->d = 0.0; st->alpha = 0.0; st->beta = 0.0;
+    const double res = sqrt(rr);
+    st->overflow = 0;
+    if (res_cap >= 1) res_norm[0] = res; else st->overflow = 1;
+    st->done = !((1 < maxit) && (res > st->tol));
+  }
+}
+// Loop step 1:  d = p'Ap (from partials); alpha = num/d; x += alpha p; r -= alpha Ap; partial r'r.
+// num = r'z (pcg, cg.jl:95) or r'r (cg, cg.jl:38).
+__global__ __launch_bounds__(NT) void k_update_xr(int n, SolverState *st, const double *part_pAp, int g_in,
+                                                  const double *__restrict__ p, const double *__restrict__ Ap,
+                                                  double *__restrict__ x, double *__restrict__ r,
+                                                  double *__restrict__ part_rr, int precond) {
+  if (st->done) return;
+  __shared__ double sm[NT / 64 + 1];
+  const double d = sum_partials(part_pAp, g_in, sm);
+  const double num = precond ? st->rTz : st->rTr;
+  const double alpha = num / d;
+  double srr = 0.0;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    const double pi = p[i];
+    x[i] = x[i] + alpha * pi;          // axpy!(alpha, p, x)
+    const double ri = r[i] + (-alpha) * Ap[i];  // axpy!(-alpha, Ap, r)
+    r[i] = ri;
+    srr += ri * ri;
+  }
+  srr = block_sum(srr, sm);
+  if (threadIdx.x == 0) {
+    part_rr[blockIdx.x] = srr;
+    if (blockIdx.x == 0) {
+      st->d = d; st->alpha = alpha;
+      st->rTr_prev = st->rTr; st->rTz_prev = st->rTz;
+    }
+  }
+}
+// Loop step 2:  r'r, r'z from partials; beta = (1/old)*new (cg.jl:39,44 / 96,102);
+// p = beta p + z [- W mu] (cg.jl:45 / 103; defcg.jl:78 / 303); it += 1; res_norm[it] = sqrt(r'r); stop rule.
+__global__ __launch_bounds__(NT) void k_update_p(int n, SolverState *st, const double *part_rr,
+                                                 const double *part_rz, int g_in, const double *__restrict__ z,
+                                                 double *__restrict__ p, const double *__restrict__ W,
+                                                 const double *__restrict__ mu, int nvec, double *res_norm,
+                                                 int precond) {
+  __shared__ double sm[NT / 64 + 1];
+  __shared__ int was_done;  // thread 0 of workgroup 0 sets st->done below: take one uniform snapshot
+  if (threadIdx.x == 0) was_done = st->done;
+  __syncthreads();
+  if (was_done) return;
+  const double rr = sum_partials(part_rr, g_in, sm);
+  const double rz = precond ? sum_partials(part_rz, g_in, sm) : rr;
+  const double old = precond ? st->rTz_prev : st->rTr_prev;
+  double beta = 1. / old;
+  beta *= rz;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    double v = beta * p[i] + z[i];     // axpby!(1, z, beta, p)
+    if (nvec > 0) {
+      double wm = 0.0;                 // (W*mu)[i], column-axpy order
+      for (int k = 0; k < nvec; ++k) wm += W[(long long)k * n + i] * mu[k];
+      v = v - wm;
+    }
+    p[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->rTr = rr; st->rTz = rz; st->beta = beta;
+    const long long it = st->it + 1;
+    st->it = it;
+    const double res = sqrt(rr);
+    if (it <= st->res_cap) res_norm[it - 1] = res; else st->overflow = 1;
+    st->done = !((it < st->maxit) && (res > st->tol));
+  }
+}
+// Set-up of the deflated solvers: p = z - W mu (defcg.jl:61 / 285); plain copy when nvec == 0.
+__global__ __launch_bounds__(NT) void k_init_p(int n, const double *__restrict__ z, double *__restrict__ p,
+                                               const double *__restrict__ W, const double *__restrict__ mu, int nvec) {
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    double v = z[i];
+    if (nvec > 0) {
+      double wm = 0.0;
+      for (int k = 0; k < nvec; ++k) wm += W[(long long)k * n + i] * mu[k];
+      v = v - wm;
+    }
+    p[i] = v;
+  }
+}
+// x += W mu (defcg.jl:54 / 275)
+__global__ __launch_bounds__(NT) void k_add_Wmu(int n, double *__restrict__ x, const double *__restrict__ W,
+                                                const double *__restrict__ mu, int nvec) {
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    double wm = 0.0;
+    for (int k = 0; k < nvec; ++k) wm += W[(long long)k * n + i] * mu[k];
+    x[i] = x[i] + wm;
+  }
+}
+// part[v*gx + g] = partial of V[:,v] . z   (V = AW for `WtA*z`, V = W for `W'r`); grid (gx, nvec)
+__global__ __launch_bounds__(NT) void k_multi_dot_partial(int n, const double *__restrict__ V,
+                                                          const double *__restrict__ z, double *__restrict__ part,
+                                                          const int *done) {
+  if (done && *done) return;
+  __shared__ double sm[NT / 64 + 1];
+  const double *v = V + (long long)blockIdx.y * n;
+  double s = 0.0;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) s += v[i] * z[i];
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+// C[i + j*nvec] = partial-free small gemm entry AW[:,i] . W[:,j]; grid (nvec, nvec), one workgroup each.
+__global__ __launch_bounds__(NT) void k_small_gram(int n, const double *__restrict__ AW, const double *__restrict__ W,
+                                                   double *__restrict__ C, int nvec) {
+  __shared__ double sm[NT / 64 + 1];
+  const double *a = AW + (long long)blockIdx.x * n;
+  const double *b = W + (long long)blockIdx.y * n;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += NT) s += a[i] * b[i];
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) C[blockIdx.x + (long long)blockIdx.y * nvec] = s;
+}
+// mu = WtAW \ rhs with rhs[v] = sum of partials; LU (unit lower L, U) and pivots from the host
+// factorisation (LAPACK getrf/getrs order: all row swaps, forward, backward). One wave.
+__global__ __launch_bounds__(64) void k_lu_solve(int nvec, const double *__restrict__ LU, const int *__restrict__ piv,
+                                                 const double *__restrict__ part, int gx, double *__restrict__ mu,
+                                                 const int *done) {
+  if (done && *done) return;
+  extern __shared__ double bsh[];
+  for (int v = threadIdx.x; v < nvec; v += 64) {
+    double s = 0.0;
+    for (int g = 0; g < gx; ++g) s += part[v * gx + g];
+    bsh[v] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int k = 0; k < nvec; ++k) {
+      const int pk = piv[k];
+      if (pk != k) { const double t = bsh[k]; bsh[k] = bsh[pk]; bsh[pk] = t; }
+    }
+  __syncthreads();
+  for (int k = 0; k < nvec; ++k) {
+    const double bk = bsh[k];
+    for (int i = k + 1 + threadIdx.x; i < nvec; i += 64) bsh[i] -= bk * LU[i + (long long)k * nvec];
+    __syncthreads();
+  }
+  for (int k = nvec - 1; k >= 0; --k) {
+    if (threadIdx.x == 0) bsh[k] /= LU[k + (long long)k * nvec];
+    __syncthreads();
+    const double bk = bsh[k];
+    for (int i = threadIdx.x; i < k; i += 64) bsh[i] -= bk * LU[i + (long long)k * nvec];
+    __syncthreads();
+  }
+  for (int v = threadIdx.x; v < nvec; v += 64) mu[v] = bsh[v];
+}
+// y = a - b (matrix-free: Sdxd .-= A_IΓdd' * v, EPDD.jl:652)
+__global__ __launch_bounds__(NT) void k_sub(int n, const double *__restrict__ a, const double *__restrict__ b,
+                                            double *__restrict__ y) {
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) y[i] = a[i] - b[i];
+}
+
+}  // namespace mi

@@ -1,0 +1,443 @@
+// extern "C" surface of libmi355schur (see include/mi355schur.h for the contract of every symbol).
+#include <dlfcn.h>
+
+#include <tuple>
+
+#include "solvers.hpp"
+
+namespace mi {
+
+Rccl &Rccl::get() {
+  static Rccl r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    // Prefer an RCCL that is already in the process (e.g. the one torch loaded), else the system one.
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+      r.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (r.handle) break;
+    }
+    if (r.handle) {
+      r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
+      r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
+      r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+      r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
+      r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+    }
+  }
+  if (!r.handle || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString)
+    raise(MI_ERR_COMM, "librccl could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+  return r;
+}
+
+// Input vector in the caller's pointer mode -> device pointer valid on ctx->stream.
+struct In {
+  const double *dev;
+  In(mi_ctx_s *c, const double *p, size_t n, DevBuf<double> &stage) {
+    if (c->ptr_mode == MI_PTR_DEVICE || n == 0) { dev = p; return; }
+    stage.ensure(n);
+    MI_HIP(hipMemcpyAsync(stage.p, p, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    dev = stage.p;
+  }
+};
+// In/out vector: staged on entry, copied back by finish().
+struct InOut {
+  mi_ctx_s *c; double *user; double *dev; size_t n; bool staged;
+  InOut(mi_ctx_s *c_, double *p, size_t n_, DevBuf<double> &stage, bool read) : c(c_), user(p), n(n_) {
+    staged = c->ptr_mode != MI_PTR_DEVICE && n > 0;
+    if (!staged) { dev = p; return; }
+    stage.ensure(n);
+    dev = stage.p;
+    if (read) MI_HIP(hipMemcpyAsync(dev, p, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  void finish() {
+    if (staged) {
+      MI_HIP(hipMemcpyAsync(user, dev, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      MI_HIP(hipStreamSynchronize(c->stream));
+    }
+  }
+};
+
+static double reduce_to_host(mi_ctx_s *c, int g, int take_sqrt) {
+  c->scalar.ensure(1);
+  hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(NT), 0, c->stream, c->partials.p, g, c->scalar.p, take_sqrt);
+  MI_HIP(hipGetLastError());
+  double out = 0.0;
+  MI_HIP(hipMemcpyAsync(&out, c->scalar.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MI_HIP(hipStreamSynchronize(c->stream));
+  return out;
+}
+
+static int run_solver(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec, int64_t maxit,
+                      double eps, double *res_norm, int64_t res_cap, int64_t *it, bool want_M, bool want_W) {
+  if (!A || !A->impl || !b || !x || !it || res_cap < 0 || (res_cap > 0 && !res_norm) || maxit < 0)
+    return fail(MI_ERR_BAD_ARG, "solver: NULL or negative argument");
+  if (want_M && (!M || !M->impl)) return fail(MI_ERR_BAD_ARG, "solver: preconditioner handle is NULL");
+  if (want_W && (nvec < 0 || (nvec > 0 && !W) || nvec > 1024)) return fail(MI_ERR_BAD_ARG, "solver: bad W / nvec");
+  Operator *a = A->impl.get(), *m = want_M ? M->impl.get() : nullptr;
+  if (m && (m->n != a->n || m->ctx != a->ctx)) return fail(MI_ERR_BAD_ARG, "solver: A and M differ in size or context");
+  mi_ctx_s *c = a->ctx;
+  return guarded([&]() -> int {
+    c->use();
+    const size_t n = (size_t)a->n;
+    In bi(c, b, n, c->scratch_a);
+    InOut xi(c, x, n, c->scratch_b, true);
+    DevBuf<double> wstage;
+    In wi(c, W, want_W ? n * (size_t)nvec : 0, wstage);
+    Krylov k(c, a, m, want_W ? (int)nvec : 0);
+    const int rc = k.solve(bi.dev, xi.dev, wi.dev, maxit, eps, res_norm, res_cap, it);
+    xi.finish();
+    return rc;
+  });
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" {
+
+int mi_version(void) { return 100; }  // 0.1.0
+const char *mi_last_error(void) { return last_error().c_str(); }
+
+int mi_device_count(int *count) {
+  if (!count) return fail(MI_ERR_BAD_ARG, "count is NULL");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  *count = n;
+  return MI_OK;
+}
+
+int mi_ctx_create(int device, mi_ctx_t *ctx) {
+  if (!ctx) return fail(MI_ERR_BAD_ARG, "ctx is NULL");
+  *ctx = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(MI_ERR_NO_DEVICE, "no HIP device visible: libmi355schur has no CPU fallback");
+  if (device < 0 || device >= n) return fail(MI_ERR_BAD_ARG, "device %d out of range [0,%d)", device, n);
+  return guarded([&]() -> int {
+    hipDeviceProp_t prop;
+    MI_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("MI355_ALLOW_ANY_ARCH"))
+      return fail(MI_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    std::unique_ptr<mi_ctx_s> c(new mi_ctx_s);
+    c->device = device;
+    c->use();
+    MI_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    c->chunk = env_int("MI355_CHUNK", 8);
+    c->partials.alloc(MAX_PARTS);
+    c->scalar.alloc(1);
+    *ctx = c.release();
+    return MI_OK;
+  });
+}
+
+int mi_ctx_destroy(mi_ctx_t ctx) {
+  if (!ctx) return MI_OK;
+  return guarded([&]() -> int {
+    ctx->use();
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->workspaces.clear();
+    if (ctx->comm) (void)Rccl::get().CommDestroy(ctx->comm);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return MI_OK;
+  });
+}
+
+int mi_ctx_set_pointer_mode(mi_ctx_t ctx, int mode) {
+  if (!ctx || (mode != MI_PTR_HOST && mode != MI_PTR_DEVICE)) return fail(MI_ERR_BAD_ARG, "bad ctx or pointer mode");
+  ctx->ptr_mode = mode;
+  return MI_OK;
+}
+
+int mi_ctx_set_stream(mi_ctx_t ctx, void *hip_stream) {
+  if (!ctx) return fail(MI_ERR_BAD_ARG, "ctx is NULL");
+  return guarded([&]() -> int {
+    ctx->use();
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &kv : ctx->workspaces) kv.second->drop_graphs();  // graphs are tied to the capture stream
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return MI_OK;
+  });
+}
+
+int mi_ctx_get_stream(mi_ctx_t ctx, void **hip_stream) {
+  if (!ctx || !hip_stream) return fail(MI_ERR_BAD_ARG, "NULL argument");
+  *hip_stream = (void *)ctx->stream;
+  return MI_OK;
+}
+
+int mi_ctx_synchronize(mi_ctx_t ctx) {
+  if (!ctx) return fail(MI_ERR_BAD_ARG, "ctx is NULL");
+  return guarded([&]() -> int { ctx->use(); MI_HIP(hipStreamSynchronize(ctx->stream)); return MI_OK; });
+}
+
+int mi_ctx_set_chunk(mi_ctx_t ctx, int iterations_per_graph) {
+  if (!ctx || iterations_per_graph < 0 || iterations_per_graph > 4096) return fail(MI_ERR_BAD_ARG, "bad ctx or chunk");
+  ctx->chunk = iterations_per_graph;
+  return MI_OK;
+}
+
+// ---------------------------------------------------------------- multi-GPU
+int mi_comm_unique_id(void *id_out) {
+  if (!id_out) return fail(MI_ERR_BAD_ARG, "id_out is NULL");
+  return guarded([&]() -> int {
+    static_assert(sizeof(ncclUniqueId) == MI_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    MI_NCCL(Rccl::get().GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof id);
+    return MI_OK;
+  });
+}
+
+int mi_ctx_comm_init(mi_ctx_t ctx, const void *id, int rank, int n_ranks) {
+  if (!ctx || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(MI_ERR_BAD_ARG, "bad communicator arguments");
+  return guarded([&]() -> int {
+    ctx->use();
+    if (ctx->comm) { MI_NCCL(Rccl::get().CommDestroy(ctx->comm)); ctx->comm = nullptr; }
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    MI_NCCL(Rccl::get().CommInitRank(&ctx->comm, n_ranks, uid, rank));
+    ctx->rank = rank; ctx->n_ranks = n_ranks;
+    for (auto &kv : ctx->workspaces) kv.second->drop_graphs();
+    return MI_OK;
+  });
+}
+
+int mi_ctx_comm_destroy(mi_ctx_t ctx) {
+  if (!ctx) return fail(MI_ERR_BAD_ARG, "ctx is NULL");
+  return guarded([&]() -> int {
+    ctx->use();
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &kv : ctx->workspaces) kv.second->drop_graphs();
+    if (ctx->comm) MI_NCCL(Rccl::get().CommDestroy(ctx->comm));
+    ctx->comm = nullptr; ctx->rank = 0; ctx->n_ranks = 1;
+    return MI_OK;
+  });
+}
+
+int mi_ctx_allreduce_sum(mi_ctx_t ctx, double *buf, int64_t n) {
+  if (!ctx || !buf || n < 0) return fail(MI_ERR_BAD_ARG, "bad allreduce arguments");
+  return guarded([&]() -> int {
+    ctx->use();
+    InOut v(ctx, buf, (size_t)n, ctx->scratch_a, true);
+    if (ctx->comm) MI_NCCL(Rccl::get().AllReduce(v.dev, v.dev, (size_t)n, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    v.finish();
+    return MI_OK;
+  });
+}
+
+// ---------------------------------------------------------------- operators
+#define MI_NEW_OP(ctx, op, expr)                                   \
+  if (!(ctx) || !(op)) return fail(MI_ERR_BAD_ARG, "ctx/op is NULL"); \
+  *(op) = nullptr;                                                 \
+  return guarded([&]() -> int {                                    \
+    (ctx)->use();                                                  \
+    std::unique_ptr<mi_op_s> h(new mi_op_s);                       \
+    h->impl.reset(expr);                                           \
+    MI_HIP(hipStreamSynchronize((ctx)->stream));                   \
+    *(op) = h.release();                                           \
+    return MI_OK;                                                  \
+  })
+
+int mi_csr_create(mi_ctx_t ctx, int64_t n_rows, int64_t n_cols, const int64_t *rowptr, const int64_t *colidx,
+                  const double *val, int index_base, mi_op_t *op) {
+  MI_NEW_OP(ctx, op, new CsrOp(ctx, host_csr(n_rows, n_cols, rowptr, colidx, val, index_base)));
+}
+
+int mi_diag_create(mi_ctx_t ctx, int64_t n, const double *dinv, mi_op_t *op) {
+  if (n < 0 || n >= INT32_MAX) return fail(MI_ERR_BAD_ARG, "bad n");
+  MI_NEW_OP(ctx, op, new DiagOp(ctx, n, dinv));
+}
+
+int mi_schur_assembled_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d,
+                              const int64_t *const *gather_idx, const double *const *Sd, int index_base,
+                              int64_t dom_begin, int64_t dom_end, mi_op_t *op) {
+  MI_NEW_OP(ctx, op, new DenseBlockOp(ctx, ndom, n_gamma, n_gamma_d, gather_idx, Sd, nullptr, index_base, dom_begin, dom_end));
+}
+
+int mi_nn_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d, const int64_t *const *gather_idx,
+                 const double *const *PiSd, const int64_t *node_gamma_cnt, int index_base, int64_t dom_begin,
+                 int64_t dom_end, mi_op_t *op) {
+  if (!node_gamma_cnt) return fail(MI_ERR_BAD_ARG, "node_gamma_cnt is NULL");
+  MI_NEW_OP(ctx, op, new DenseBlockOp(ctx, ndom, n_gamma, n_gamma_d, gather_idx, PiSd, node_gamma_cnt, index_base, dom_begin, dom_end));
+}
+
+int mi_schur_matfree_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d, const int64_t *n_i,
+                            const int64_t *const *gather_idx, const int64_t *const *ig_colptr,
+                            const int64_t *const *ig_rowval, const double *const *ig_nzval,
+                            const int64_t *const *gg_colptr, const int64_t *const *gg_rowval,
+                            const double *const *gg_nzval, mi_interior_solve_fn solve, void *user, int index_base,
+                            int64_t dom_begin, int64_t dom_end, mi_op_t *op) {
+  MI_NEW_OP(ctx, op, new MatfreeSchurOp(ctx, ndom, n_gamma, n_gamma_d, n_i, gather_idx, ig_colptr, ig_rowval, ig_nzval,
+                                        gg_colptr, gg_rowval, gg_nzval, solve, user, index_base, dom_begin, dom_end));
+}
+
+int mi_schur_global_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_i,
+                           const int64_t *const *ig_colptr, const int64_t *const *ig_rowval,
+                           const double *const *ig_nzval, const int64_t *gg_colptr, const int64_t *gg_rowval,
+                           const double *gg_nzval, mi_interior_solve_fn solve, void *user, int index_base, mi_op_t *op) {
+  MI_NEW_OP(ctx, op, new GlobalSchurOp(ctx, ndom, n_gamma, n_i, ig_colptr, ig_rowval, ig_nzval, gg_colptr, gg_rowval,
+                                       gg_nzval, solve, user, index_base));
+}
+
+int mi_op_size(mi_op_t op, int64_t *n) {
+  if (!op || !op->impl || !n) return fail(MI_ERR_BAD_ARG, "NULL argument");
+  *n = op->impl->n;
+  return MI_OK;
+}
+
+int mi_op_apply(mi_op_t op, const double *x, double *y) {
+  if (!op || !op->impl || !x || !y || x == y) return fail(MI_ERR_BAD_ARG, "mi_op_apply: NULL or aliased argument");
+  return guarded([&]() -> int {
+    mi_ctx_s *c = op->impl->ctx;
+    c->use();
+    const size_t n = (size_t)op->impl->n;
+    In xi(c, x, n, op->hx);
+    InOut yo(c, y, n, op->hy, false);
+    op->impl->apply(xi.dev, yo.dev, nullptr);
+    yo.finish();
+    return MI_OK;
+  });
+}
+
+int mi_op_bytes(mi_op_t op, int64_t *bytes_apply, int64_t *bytes_dominant_kernel) {
+  if (!op || !op->impl) return fail(MI_ERR_BAD_ARG, "op is NULL");
+  int64_t a = 0, d = 0;
+  op->impl->bytes(&a, &d);
+  if (bytes_apply) *bytes_apply = a;
+  if (bytes_dominant_kernel) *bytes_dominant_kernel = d;
+  return MI_OK;
+}
+
+int mi_op_apply_dominant(mi_op_t op, const double *x, int reps) {
+  if (!op || !op->impl || !x || reps < 0) return fail(MI_ERR_BAD_ARG, "bad argument");
+  return guarded([&]() -> int {
+    mi_ctx_s *c = op->impl->ctx;
+    c->use();
+    In xi(c, x, (size_t)op->impl->n, op->hx);
+    for (int i = 0; i < reps; ++i) op->impl->apply_dominant(xi.dev);
+    return MI_OK;
+  });
+}
+
+int mi_op_destroy(mi_op_t op) {
+  if (!op) return MI_OK;
+  return guarded([&]() -> int {
+    if (op->impl) {
+      mi_ctx_s *c = op->impl->ctx;
+      c->use();
+      (void)hipStreamSynchronize(c->stream);
+      for (auto &kv : c->workspaces) kv.second->drop_graphs_of(op->impl.get());
+    }
+    delete op;
+    return MI_OK;
+  });
+}
+
+// ---------------------------------------------------------------- BLAS-1
+int mi_dot(mi_ctx_t ctx, int64_t n, const double *x, const double *y, double *result) {
+  if (!ctx || n < 0 || n >= INT32_MAX || !x || !y || !result) return fail(MI_ERR_BAD_ARG, "mi_dot: bad argument");
+  return guarded([&]() -> int {
+    ctx->use();
+    In xi(ctx, x, (size_t)n, ctx->scratch_a), yi(ctx, y, (size_t)n, ctx->scratch_b);
+    const int g = vec_grid(n);
+    hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(NT), 0, ctx->stream, (int)n, xi.dev, yi.dev, ctx->partials.p,
+                       (const int *)nullptr);
+    *result = reduce_to_host(ctx, g, 0);
+    return MI_OK;
+  });
+}
+
+int mi_norm2(mi_ctx_t ctx, int64_t n, const double *x, double *result) {
+  if (!ctx || n < 0 || n >= INT32_MAX || !x || !result) return fail(MI_ERR_BAD_ARG, "mi_norm2: bad argument");
+  return guarded([&]() -> int {
+    ctx->use();
+    In xi(ctx, x, (size_t)n, ctx->scratch_a);
+    const int g = vec_grid(n);
+    hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(NT), 0, ctx->stream, (int)n, xi.dev, xi.dev, ctx->partials.p,
+                       (const int *)nullptr);
+    *result = reduce_to_host(ctx, g, 1);
+    return MI_OK;
+  });
+}
+
+int mi_axpy(mi_ctx_t ctx, int64_t n, double a, const double *x, double *y) {
+  if (!ctx || n < 0 || n >= INT32_MAX || !x || !y) return fail(MI_ERR_BAD_ARG, "mi_axpy: bad argument");
+  return guarded([&]() -> int {
+    ctx->use();
+    In xi(ctx, x, (size_t)n, ctx->scratch_a);
+    InOut yo(ctx, y, (size_t)n, ctx->scratch_b, true);
+    hipLaunchKernelGGL(k_axpy, dim3(vec_grid(n)), dim3(NT), 0, ctx->stream, (int)n, a, xi.dev, yo.dev);
+    MI_HIP(hipGetLastError());
+    yo.finish();
+    return MI_OK;
+  });
+}
+
+int mi_axpby(mi_ctx_t ctx, int64_t n, double a, const double *x, double b, double *y) {
+  if (!ctx || n < 0 || n >= INT32_MAX || !x || !y) return fail(MI_ERR_BAD_ARG, "mi_axpby: bad argument");
+  return guarded([&]() -> int {
+    ctx->use();
+    In xi(ctx, x, (size_t)n, ctx->scratch_a);
+    InOut yo(ctx, y, (size_t)n, ctx->scratch_b, true);
+    hipLaunchKernelGGL(k_axpby, dim3(vec_grid(n)), dim3(NT), 0, ctx->stream, (int)n, a, xi.dev, b, yo.dev);
+    MI_HIP(hipGetLastError());
+    yo.finish();
+    return MI_OK;
+  });
+}
+
+// ---------------------------------------------------------------- solvers
+int mi_cg(mi_op_t A, const double *b, double *x, int64_t maxit, double eps, double *res_norm, int64_t res_cap,
+          int64_t *it) {
+  return run_solver(A, nullptr, b, x, nullptr, 0, maxit, eps, res_norm, res_cap, it, false, false);
+}
+int mi_pcg(mi_op_t A, mi_op_t M, const double *b, double *x, int64_t maxit, double eps, double *res_norm,
+           int64_t res_cap, int64_t *it) {
+  return run_solver(A, M, b, x, nullptr, 0, maxit, eps, res_norm, res_cap, it, true, false);
+}
+int mi_defcg(mi_op_t A, const double *b, double *x, const double *W, int64_t nvec, int64_t maxit, double eps,
+             double *res_norm, int64_t res_cap, int64_t *it) {
+  return run_solver(A, nullptr, b, x, W, nvec, maxit, eps, res_norm, res_cap, it, false, true);
+}
+int mi_defpcg(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec, int64_t maxit,
+              double eps, double *res_norm, int64_t res_cap, int64_t *it) {
+  return run_solver(A, M, b, x, W, nvec, maxit, eps, res_norm, res_cap, it, true, true);
+}
+
+// ---------------------------------------------------------------- events
+int mi_event_create(mi_event_t *ev) {
+  if (!ev) return fail(MI_ERR_BAD_ARG, "ev is NULL");
+  return guarded([&]() -> int {
+    std::unique_ptr<mi_event_s> e(new mi_event_s);
+    MI_HIP(hipEventCreate(&e->ev));
+    *ev = e.release();
+    return MI_OK;
+  });
+}
+int mi_event_record(mi_ctx_t ctx, mi_event_t ev) {
+  if (!ctx || !ev) return fail(MI_ERR_BAD_ARG, "NULL argument");
+  return guarded([&]() -> int { ctx->use(); MI_HIP(hipEventRecord(ev->ev, ctx->stream)); return MI_OK; });
+}
+int mi_event_elapsed_ms(mi_event_t start, mi_event_t stop, double *ms) {
+  if (!start || !stop || !ms) return fail(MI_ERR_BAD_ARG, "NULL argument");
+  return guarded([&]() -> int {
+    MI_HIP(hipEventSynchronize(stop->ev));
+    float t = 0.f;
+    MI_HIP(hipEventElapsedTime(&t, start->ev, stop->ev));
+    *ms = (double)t;
+    return MI_OK;
+  });
+}
+int mi_event_destroy(mi_event_t ev) {
+  if (!ev) return MI_OK;
+  (void)hipEventDestroy(ev->ev);
+  delete ev;
+  return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,428 @@
+// Operators (`A*x`, `mul!`) and preconditioners (`M \ r`) of the hot path, device resident.
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+#include <numeric>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace mi {
+
+inline int vec_grid(int64_t n) {
+  int64_t g = (n + (int64_t)NT * 4 - 1) / ((int64_t)NT * 4);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, MAX_PARTS));
+}
+inline int env_int(const char *name, int dflt) {
+  const char *s = std::getenv(name);
+  return s && *s ? std::atoi(s) : dflt;
+}
+inline int to_i32(int64_t v, int64_t lo, int64_t hi, const char *what) {
+  if (v < lo || v >= hi) raise(MI_ERR_BAD_ARG, "%s: index %lld outside [%lld, %lld)", what, (long long)v,
+                               (long long)lo, (long long)hi);
+  return (int)v;
+}
+
+// ------------------------------------------------------------------ base class
+struct Operator {
+  mi_ctx_s *ctx;
+  int64_t n;  // operator is n x n on the Γ (or full) vector space
+  Operator(mi_ctx_s *c, int64_t n_) : ctx(c), n(n_) {}
+  virtual ~Operator() = default;
+  // Enqueue y = Op(x) on ctx->stream; x, y are device pointers, x != y.
+  virtual void apply(const double *x, double *y, const int *done) = 0;
+  virtual bool graph_safe() const { return true; }  // false: apply synchronises with the host
+  virtual void bytes(int64_t *apply_b, int64_t *dominant_b) const = 0;
+  virtual void apply_dominant(const double *x) = 0;
+};
+
+// ------------------------------------------------------------------ CSR storage on the device
+struct HostCsr {
+  int n_rows = 0, n_cols = 0;
+  std::vector<int> rowptr, col;
+  std::vector<double> val;
+  int64_t nnz() const { return (int64_t)col.size(); }
+};
+// CSR arrays given as int64 + base -> checked int32 host CSR
+inline HostCsr host_csr(int64_t n_rows, int64_t n_cols, const int64_t *rowptr, const int64_t *colidx,
+                        const double *val, int base) {
+  if (n_rows < 0 || n_cols < 0 || !rowptr || n_rows >= INT32_MAX || n_cols >= INT32_MAX)
+    raise(MI_ERR_BAD_ARG, "csr: bad shape or NULL rowptr");
+  HostCsr h;
+  h.n_rows = (int)n_rows; h.n_cols = (int)n_cols;
+  h.rowptr.resize(n_rows + 1);
+  const int64_t nnz = rowptr[n_rows] - base;
+  if (rowptr[0] != base || nnz < 0 || nnz >= INT32_MAX) raise(MI_ERR_BAD_ARG, "csr: bad rowptr[0]/nnz");
+  if (nnz && (!colidx || !val)) raise(MI_ERR_BAD_ARG, "csr: NULL colidx/val");
+  for (int64_t i = 0; i <= n_rows; ++i) {
+    const int64_t v = rowptr[i] - base;
+    if (v < 0 || v > nnz || (i && v < h.rowptr[i - 1])) raise(MI_ERR_BAD_ARG, "csr: rowptr not monotone");
+    h.rowptr[i] = (int)v;
+  }
+  h.col.resize(nnz); h.val.assign(val, val + nnz);
+  for (int64_t k = 0; k < nnz; ++k) h.col[k] = to_i32(colidx[k] - base, 0, n_cols, "csr colidx");
+  return h;
+}
+// transpose (stable: column order inside every output row is ascending source row)
+inline HostCsr transpose(const HostCsr &a) {
+  HostCsr t;
+  t.n_rows = a.n_cols; t.n_cols = a.n_rows;
+  t.rowptr.assign(t.n_rows + 1, 0);
+  for (int c : a.col) t.rowptr[c + 1]++;
+  std::partial_sum(t.rowptr.begin(), t.rowptr.end(), t.rowptr.begin());
+  t.col.resize(a.col.size()); t.val.resize(a.val.size());
+  std::vector<int> next(t.rowptr.begin(), t.rowptr.end() - 1);
+  for (int r = 0; r < a.n_rows; ++r)
+    for (int k = a.rowptr[r]; k < a.rowptr[r + 1]; ++k) {
+      const int q = next[a.col[k]]++;
+      t.col[q] = r; t.val[q] = a.val[k];
+    }
+  return t;
+}
+// append `b` below/right of `a` (block-diagonal when col_shift > 0, vertical stack when 0)
+inline void append_block(HostCsr &a, const HostCsr &b, int col_shift, int new_cols) {
+  const int base = (int)a.col.size();
+  if (a.rowptr.empty()) a.rowptr.push_back(0);
+  for (int r = 0; r < b.n_rows; ++r) a.rowptr.push_back(base + b.rowptr[r + 1]);
+  for (size_t k = 0; k < b.col.size(); ++k) { a.col.push_back(b.col[k] + col_shift); a.val.push_back(b.val[k]); }
+  a.n_rows += b.n_rows; a.n_cols = new_cols;
+}
+
+struct CsrDev {
+  int n_rows = 0, n_cols = 0, nblocks = 0;
+  int64_t nnz = 0;
+  DevBuf<int> rowptr, col, rb;
+  DevBuf<double> val;
+  void upload(const HostCsr &h, hipStream_t s) {
+    n_rows = h.n_rows; n_cols = h.n_cols; nnz = h.nnz();
+    std::vector<int> blocks{0};
+    int r = 0;
+    while (r < n_rows) {  // greedy row blocks of <= SPMV_TILE non-zeros (a longer row stands alone)
+      int e = r + 1;
+      while (e < n_rows && h.rowptr[e + 1] - h.rowptr[r] <= SPMV_TILE) ++e;
+      blocks.push_back(e);
+      r = e;
+    }
+    nblocks = (int)blocks.size() - 1;
+    std::vector<int> rp = h.rowptr;
+    if (rp.empty()) rp.push_back(0);
+    rowptr.upload(rp, s); col.upload(h.col, s); val.upload(h.val, s); rb.upload(blocks, s);
+  }
+  // y = A x (mode 0) or y = yin - A x (mode 1)
+  void launch(int mode, const double *x, const double *yin, double *y, const int *done, hipStream_t s) const {
+    if (nblocks == 0) return;
+    const int grid = ((nblocks + 7) / 8) * 8;
+    if (mode == 0)
+      hipLaunchKernelGGL(k_spmv_csr<0>, dim3(grid), dim3(NT), 0, s, nblocks, rb.p, rowptr.p, col.p, val.p, x,
+                         (const double *)nullptr, y, done);
+    else
+      hipLaunchKernelGGL(k_spmv_csr<1>, dim3(grid), dim3(NT), 0, s, nblocks, rb.p, rowptr.p, col.p, val.p, x, yin, y,
+                         done);
+    MI_HIP(hipGetLastError());
+  }
+  // 12 nnz + 4 (rows+1) + 8 cols (x once) + 8 rows (y)
+  int64_t bytes() const { return 12 * nnz + 4 * ((int64_t)n_rows + 1) + 8 * (int64_t)n_cols + 8 * (int64_t)n_rows; }
+};
+
+// ------------------------------------------------------------------ SparseMatrixCSC `A`
+struct CsrOp : Operator {
+  CsrDev A;
+  DevBuf<double> sink;
+  CsrOp(mi_ctx_s *c, const HostCsr &h) : Operator(c, h.n_rows) {
+    if (h.n_rows != h.n_cols) raise(MI_ERR_BAD_ARG, "mi_csr_create: solver operators must be square");
+    A.upload(h, c->stream);
+  }
+  void apply(const double *x, double *y, const int *done) override { A.launch(0, x, nullptr, y, done, ctx->stream); }
+  void bytes(int64_t *a, int64_t *d) const override { *a = *d = A.bytes(); }
+  void apply_dominant(const double *x) override {
+    sink.ensure((size_t)n);
+    A.launch(0, x, nullptr, sink.p, nullptr, ctx->stream);
+  }
+};
+
+// ------------------------------------------------------------------ diagonal / identity `M`
+struct DiagOp : Operator {
+  DevBuf<double> dinv;
+  bool identity;
+  DiagOp(mi_ctx_s *c, int64_t n_, const double *d) : Operator(c, n_), identity(d == nullptr) {
+    if (d) { dinv.upload(d, (size_t)n_, c->stream); MI_HIP(hipStreamSynchronize(c->stream)); }
+  }
+  void apply(const double *x, double *y, const int *done) override {
+    hipLaunchKernelGGL(k_diag_apply, dim3(vec_grid(n)), dim3(NT), 0, ctx->stream, (int)n,
+                       identity ? (const double *)nullptr : dinv.p, x, y, done);
+    MI_HIP(hipGetLastError());
+  }
+  void bytes(int64_t *a, int64_t *d) const override { *a = *d = (identity ? 16 : 24) * n; }
+  void apply_dominant(const double *) override {}
+};
+
+// ------------------------------------------------------------------ local-to-Γ bookkeeping shared by the Schur ops
+struct LocalMaps {
+  int ndl = 0;   // local subdomains on this rank
+  int nloc = 0;  // Σ n_Γd over local subdomains
+  std::vector<int> nd, loc_off, gidx_h;
+  DevBuf<int> gidx, aptr, apos;
+  void build(mi_ctx_s *c, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d, const int64_t *const *gather_idx,
+             int base, int64_t d0, int64_t d1) {
+    if (ndom <= 0 || n_gamma < 0 || n_gamma >= INT32_MAX || !n_gamma_d || !gather_idx || d0 < 0 || d1 > ndom || d0 > d1)
+      raise(MI_ERR_BAD_ARG, "schur/nn create: bad ndom/n_gamma/domain slice");
+    ndl = (int)(d1 - d0);
+    int64_t tot = 0;
+    for (int64_t d = d0; d < d1; ++d) {
+      if (n_gamma_d[d] < 0 || n_gamma_d[d] > n_gamma) raise(MI_ERR_BAD_ARG, "n_gamma_d[%lld] out of range", (long long)d);
+      if (n_gamma_d[d] && !gather_idx[d]) raise(MI_ERR_BAD_ARG, "gather_idx[%lld] is NULL", (long long)d);
+      loc_off.push_back((int)tot);
+      nd.push_back((int)n_gamma_d[d]);
+      tot += n_gamma_d[d];
+      if (tot >= INT32_MAX) raise(MI_ERR_BAD_ARG, "local interface too large");
+    }
+    nloc = (int)tot;
+    gidx_h.resize(nloc);
+    std::vector<int> cntv(n_gamma + 1, 0);
+    for (int dl = 0; dl < ndl; ++dl) {
+      std::vector<char> seen;  // a Dict has unique keys: each Γ node at most once per subdomain
+      seen.assign((size_t)n_gamma, 0);
+      for (int l = 0; l < nd[dl]; ++l) {
+        const int g = to_i32(gather_idx[d0 + dl][l] - base, 0, n_gamma, "gather_idx");
+        if (seen[g]) raise(MI_ERR_BAD_ARG, "gather_idx[%d] repeats Γ index %d", dl, g);
+        seen[g] = 1;
+        gidx_h[loc_off[dl] + l] = g;
+        cntv[g + 1]++;
+      }
+    }
+    // inverted index: contributions of every Γ node in ascending subdomain order
+    std::partial_sum(cntv.begin(), cntv.end(), cntv.begin());
+    std::vector<int> pos(nloc), next(cntv.begin(), cntv.end() - 1);
+    for (int dl = 0; dl < ndl; ++dl)
+      for (int l = 0; l < nd[dl]; ++l) pos[next[gidx_h[loc_off[dl] + l]]++] = loc_off[dl] + l;
+    gidx.upload(gidx_h, c->stream); aptr.upload(cntv, c->stream); apos.upload(pos, c->stream);
+  }
+  void assemble(mi_ctx_s *c, int64_t n_gamma, const double *yloc, double *y, const int *done) const {
+    hipLaunchKernelGGL(k_assemble, dim3(vec_grid(n_gamma)), dim3(NT), 0, c->stream, (int)n_gamma, aptr.p, apos.p, yloc,
+                       y, done);
+    MI_HIP(hipGetLastError());
+    c->allreduce(y, (size_t)n_gamma);
+  }
+};
+
+// ------------------------------------------------------------------ assembled Schur operator / Neumann-Neumann preconditioner
+struct DenseBlockOp : Operator {
+  LocalMaps maps;
+  bool scale;  // true: Neumann-Neumann (gather r/cnt, result /cnt)
+  int rpw, ntiles = 0;
+  DevBuf<double> M, cnt, yloc;
+  DevBuf<long long> mat_off;
+  DevBuf<int> nd, ld, loc_off, tile_dom, tile_row0;
+  int64_t alg_bytes = 0;
+  DenseMeta meta{};
+
+  DenseBlockOp(mi_ctx_s *c, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d, const int64_t *const *gather_idx,
+               const double *const *blocks, const int64_t *node_cnt, int base, int64_t d0, int64_t d1)
+      : Operator(c, n_gamma), scale(node_cnt != nullptr) {
+    if (!blocks) raise(MI_ERR_BAD_ARG, "dense blocks pointer is NULL");
+    maps.build(c, ndom, n_gamma, n_gamma_d, gather_idx, base, d0, d1);
+    rpw = env_int("MI355_GEMV_RPW", 2);
+    if (rpw != 1 && rpw != 2 && rpw != 4) rpw = 2;
+    std::vector<long long> moff;
+    std::vector<int> ldv, tdom, trow;
+    long long tot = 0;
+    for (int dl = 0; dl < maps.ndl; ++dl) {
+      const int n_d = maps.nd[dl], l = (n_d + 15) / 16 * 16;
+      if (n_d && !blocks[d0 + dl]) raise(MI_ERR_BAD_ARG, "dense block %d is NULL", dl);
+      moff.push_back(tot); ldv.push_back(l);
+      tot += (long long)n_d * l;
+      for (int r = 0; r < n_d; r += 4 * rpw) { tdom.push_back(dl); trow.push_back(r); }
+      alg_bytes += 8ll * n_d * n_d + 16ll * n_d + 4ll * n_d;
+    }
+    ntiles = (int)tdom.size();
+    M.alloc((size_t)tot);
+    // column-major (Julia) -> padded row-major, one block at a time
+    for (int dl = 0; dl < maps.ndl; ++dl) {
+      const int n_d = maps.nd[dl], l = ldv[dl];
+      std::vector<double> rowm((size_t)n_d * l, 0.0);
+      const double *src = blocks[d0 + dl];
+      for (int j = 0; j < n_d; ++j)
+        for (int i = 0; i < n_d; ++i) rowm[(size_t)i * l + j] = src[(size_t)i + (size_t)j * n_d];
+      if (!rowm.empty())
+        MI_HIP(hipMemcpy(M.p + moff[dl], rowm.data(), rowm.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (scale) {
+      std::vector<double> cv(maps.nloc);
+      for (int s = 0; s < maps.nloc; ++s) {
+        const int64_t v = node_cnt[maps.gidx_h[s]];
+        if (v <= 0) raise(MI_ERR_BAD_ARG, "node_gamma_cnt must be positive");
+        cv[s] = (double)v;
+      }
+      cnt.upload(cv, c->stream);
+    }
+    mat_off.upload(moff, c->stream); nd.upload(maps.nd, c->stream); ld.upload(ldv, c->stream);
+    loc_off.upload(maps.loc_off, c->stream); tile_dom.upload(tdom, c->stream); tile_row0.upload(trow, c->stream);
+    yloc.alloc((size_t)maps.nloc + 1);
+    yloc.zero(c->stream);
+    MI_HIP(hipStreamSynchronize(c->stream));
+    meta = DenseMeta{M.p, mat_off.p, nd.p, ld.p, loc_off.p, maps.gidx.p, scale ? cnt.p : nullptr, tile_dom.p, tile_row0.p};
+  }
+  void gemv(const double *x, const int *done) {
+    if (!ntiles) return;
+#define MI_GEMV(R, S) hipLaunchKernelGGL((k_gemv_batched<R, S>), dim3(ntiles), dim3(NT), 0, ctx->stream, meta, x, yloc.p, done)
+    if (scale) { if (rpw == 1) MI_GEMV(1, true); else if (rpw == 2) MI_GEMV(2, true); else MI_GEMV(4, true); }
+    else       { if (rpw == 1) MI_GEMV(1, false); else if (rpw == 2) MI_GEMV(2, false); else MI_GEMV(4, false); }
+#undef MI_GEMV
+    MI_HIP(hipGetLastError());
+  }
+  void apply(const double *x, double *y, const int *done) override {
+    gemv(x, done);
+    maps.assemble(ctx, n, yloc.p, y, done);
+  }
+  void bytes(int64_t *a, int64_t *d) const override { *a = alg_bytes + 8 * n; *d = alg_bytes; }
+  void apply_dominant(const double *x) override { gemv(x, nullptr); }
+};
+
+// ------------------------------------------------------------------ host staging for the interior-solve callback
+struct HostStage {
+  double *rhs = nullptr, *sol = nullptr;
+  size_t n = 0;
+  void ensure(size_t m) {
+    if (m <= n) return;
+    release();
+    MI_HIP(hipHostMalloc((void **)&rhs, (m ? m : 1) * sizeof(double)));
+    MI_HIP(hipHostMalloc((void **)&sol, (m ? m : 1) * sizeof(double)));
+    n = m;
+  }
+  void release() {
+    if (rhs) (void)hipHostFree(rhs);
+    if (sol) (void)hipHostFree(sol);
+    rhs = sol = nullptr; n = 0;
+  }
+  ~HostStage() { release(); }
+};
+
+// ------------------------------------------------------------------ matrix-free local Schur operator (EPDD.jl:711-747)
+// All local subdomains are stacked into block-diagonal CSR matrices over the concatenated local
+// spaces, so one SpMV launch serves every subdomain: rhs = A_IΓ xd ; t = A_ΓΓ xd ; yloc = t - A_ΓI v.
+struct MatfreeSchurOp : Operator {
+  LocalMaps maps;
+  CsrDev A_IG, A_GI, A_GG;
+  std::vector<int> ni, ioff;
+  int64_t d0;
+  int ni_tot = 0;
+  mi_interior_solve_fn solve; void *user;
+  DevBuf<double> xcat, rhs, sol, t1, yloc;
+  HostStage stage;
+
+  MatfreeSchurOp(mi_ctx_s *c, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d, const int64_t *n_i,
+                 const int64_t *const *gather_idx, const int64_t *const *ig_ptr, const int64_t *const *ig_idx,
+                 const double *const *ig_val, const int64_t *const *gg_ptr, const int64_t *const *gg_idx,
+                 const double *const *gg_val, mi_interior_solve_fn f, void *u, int base, int64_t d0_, int64_t d1)
+      : Operator(c, n_gamma), d0(d0_), solve(f), user(u) {
+    if (!f || !n_i || !ig_ptr || !ig_idx || !ig_val || !gg_ptr || !gg_idx || !gg_val)
+      raise(MI_ERR_BAD_ARG, "mi_schur_matfree_create: NULL argument");
+    maps.build(c, ndom, n_gamma, n_gamma_d, gather_idx, base, d0, d1);
+    HostCsr ig, gi, gg;
+    int64_t itot = 0;
+    for (int dl = 0; dl < maps.ndl; ++dl) { ioff.push_back((int)itot); ni.push_back((int)n_i[d0 + dl]); itot += n_i[d0 + dl]; }
+    if (itot >= INT32_MAX) raise(MI_ERR_BAD_ARG, "interior too large");
+    ni_tot = (int)itot;
+    for (int dl = 0; dl < maps.ndl; ++dl) {
+      const int64_t d = d0 + dl;
+      // CSC arrays of A_IΓdd (n_i x n_Γd) are the CSR arrays of A_ΓIdd = A_IΓdd' (n_Γd x n_i)
+      HostCsr gi_d = host_csr(maps.nd[dl], ni[dl], ig_ptr[d], ig_idx[d], ig_val[d], base);
+      HostCsr ig_d = transpose(gi_d);
+      HostCsr gg_d = host_csr(maps.nd[dl], maps.nd[dl], gg_ptr[d], gg_idx[d], gg_val[d], base);
+      append_block(gi, gi_d, ioff[dl], ni_tot);
+      append_block(ig, ig_d, maps.loc_off[dl], maps.nloc);
+      append_block(gg, gg_d, maps.loc_off[dl], maps.nloc);
+    }
+    if (gi.rowptr.empty()) { gi.rowptr = {0}; ig.rowptr = {0}; gg.rowptr = {0}; }
+    A_IG.upload(ig, c->stream); A_GI.upload(gi, c->stream); A_GG.upload(gg, c->stream);
+    xcat.alloc(maps.nloc + 1); t1.alloc(maps.nloc + 1); yloc.alloc(maps.nloc + 1);
+    rhs.alloc(ni_tot + 1); sol.alloc(ni_tot + 1);
+    stage.ensure(ni_tot);
+  }
+  bool graph_safe() const override { return false; }
+  void apply(const double *x, double *y, const int *) override {
+    hipStream_t s = ctx->stream;
+    if (maps.nloc) {
+      hipLaunchKernelGGL(k_gather, dim3(vec_grid(maps.nloc)), dim3(NT), 0, s, maps.nloc, maps.gidx.p, x, xcat.p);
+      MI_HIP(hipGetLastError());
+      A_IG.launch(0, xcat.p, nullptr, rhs.p, nullptr, s);
+      A_GG.launch(0, xcat.p, nullptr, t1.p, nullptr, s);
+      MI_HIP(hipMemcpyAsync(stage.rhs, rhs.p, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+      for (int dl = 0; dl < maps.ndl; ++dl)
+        if (solve(user, d0 + dl, ni[dl], stage.rhs + ioff[dl], stage.sol + ioff[dl]) != 0)
+          raise(MI_ERR_CALLBACK, "interior solve callback failed on subdomain %lld", (long long)(d0 + dl));
+      MI_HIP(hipMemcpyAsync(sol.p, stage.sol, sizeof(double) * ni_tot, hipMemcpyHostToDevice, s));
+      A_GI.launch(1, sol.p, t1.p, yloc.p, nullptr, s);
+    }
+    maps.assemble(ctx, n, yloc.p, y, nullptr);
+  }
+  void bytes(int64_t *a, int64_t *d) const override {
+    *a = A_IG.bytes() + A_GI.bytes() + A_GG.bytes() + 16ll * ni_tot;
+    *d = A_IG.bytes();
+  }
+  void apply_dominant(const double *x) override {
+    if (!maps.nloc) return;
+    hipLaunchKernelGGL(k_gather, dim3(vec_grid(maps.nloc)), dim3(NT), 0, ctx->stream, maps.nloc, maps.gidx.p, x, xcat.p);
+    A_IG.launch(0, xcat.p, nullptr, rhs.p, nullptr, ctx->stream);
+  }
+};
+
+// ------------------------------------------------------------------ apply_global_schur (EPDD.jl:596-625)
+struct GlobalSchurOp : Operator {
+  int ndom;
+  std::vector<CsrDev> A_IG, A_GI;  // per subdomain: (n_i x n_Γ) and its transpose (n_Γ x n_i)
+  CsrDev A_GG;
+  std::vector<int> ni, ioff;
+  int ni_tot = 0;
+  mi_interior_solve_fn solve; void *user;
+  DevBuf<double> rhs, sol;
+  HostStage stage;
+
+  GlobalSchurOp(mi_ctx_s *c, int64_t ndom_, int64_t n_gamma, const int64_t *n_i, const int64_t *const *ig_ptr,
+                const int64_t *const *ig_idx, const double *const *ig_val, const int64_t *gg_ptr, const int64_t *gg_idx,
+                const double *gg_val, mi_interior_solve_fn f, void *u, int base)
+      : Operator(c, n_gamma), ndom((int)ndom_), solve(f), user(u) {
+    if (!f || ndom_ <= 0 || !n_i || !ig_ptr || !ig_idx || !ig_val || !gg_ptr)
+      raise(MI_ERR_BAD_ARG, "mi_schur_global_create: NULL argument");
+    A_IG.resize(ndom); A_GI.resize(ndom);
+    int64_t itot = 0;
+    for (int d = 0; d < ndom; ++d) {
+      ioff.push_back((int)itot); ni.push_back((int)n_i[d]); itot += n_i[d];
+      if (itot >= INT32_MAX) raise(MI_ERR_BAD_ARG, "interior too large");
+      HostCsr gi_d = host_csr(n_gamma, n_i[d], ig_ptr[d], ig_idx[d], ig_val[d], base);
+      A_GI[d].upload(gi_d, c->stream);
+      A_IG[d].upload(transpose(gi_d), c->stream);
+    }
+    ni_tot = (int)itot;
+    A_GG.upload(host_csr(n_gamma, n_gamma, gg_ptr, gg_idx, gg_val, base), c->stream);
+    rhs.alloc(ni_tot + 1); sol.alloc(ni_tot + 1);
+    stage.ensure(ni_tot);
+  }
+  bool graph_safe() const override { return false; }
+  void apply(const double *x, double *y, const int *) override {
+    hipStream_t s = ctx->stream;
+    A_GG.launch(0, x, nullptr, y, nullptr, s);  // Sx = A_ΓΓ * x
+    for (int d = 0; d < ndom; ++d) A_IG[d].launch(0, x, nullptr, rhs.p + ioff[d], nullptr, s);
+    MI_HIP(hipMemcpyAsync(stage.rhs, rhs.p, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    for (int d = 0; d < ndom; ++d)
+      if (solve(user, d, ni[d], stage.rhs + ioff[d], stage.sol + ioff[d]) != 0)
+        raise(MI_ERR_CALLBACK, "interior solve callback failed on subdomain %d", d);
+    MI_HIP(hipMemcpyAsync(sol.p, stage.sol, sizeof(double) * ni_tot, hipMemcpyHostToDevice, s));
+    for (int d = 0; d < ndom; ++d) A_GI[d].launch(1, sol.p + ioff[d], y, y, nullptr, s);  // Sx .-= A_IΓd' * v
+  }
+  void bytes(int64_t *a, int64_t *dd) const override {
+    int64_t t = A_GG.bytes();
+    for (int d = 0; d < ndom; ++d) t += A_IG[d].bytes() + A_GI[d].bytes();
+    *a = t + 16ll * ni_tot; *dd = A_GG.bytes();
+  }
+  void apply_dominant(const double *) override {}
+};
+
+}  // namespace mi
+
+struct mi_op_s {
+  std::unique_ptr<mi::Operator> impl;
+  mi::DevBuf<double> hx, hy;  // staging for host-pointer mode
+};

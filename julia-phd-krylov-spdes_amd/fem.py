@@ -444,26 +444,112 @@ class InteriorSolver:
         return self.lu.solve(np.ascontiguousarray(rhs, dtype=np.float64))
 
 
-def assemble_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, solvers: Optional[Sequence[InteriorSolver]] = None,
-                          chunk: int = 256):
+def _bfs_levels_from_interface(A_II: sp.csr_matrix, seeds: np.ndarray):
+    """Breadth-first levels of the graph of A_II starting from `seeds`; nodes that are not
+    connected to the seeds are left out (they cannot influence the Schur complement)."""
+    n = A_II.shape[0]
+    level = np.full(n, -1, dtype=np.int64)
+    level[seeds] = 0
+    frontier, levels = np.asarray(seeds, dtype=np.int64), []
+    indptr, indices = A_II.indptr, A_II.indices
+    while frontier.size:
+        levels.append(frontier)
+        starts, ends = indptr[frontier], indptr[frontier + 1]
+        cnt = ends - starts
+        idx = np.repeat(starts - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt) + np.arange(cnt.sum())
+        nb = np.unique(indices[idx])
+        nb = nb[level[nb] < 0]
+        level[nb] = len(levels)
+        frontier = nb
+    return levels
+
+
+def _dense_device():
+    """Where the dense level recursion runs: the GPU through torch when one is visible (set-up
+    only — rocBLAS/rocSOLVER library calls, not part of the hot path), else torch on the CPU,
+    else numpy. scipy.linalg is avoided: its bundled OpenBLAS stalls for ~0.5 s per small
+    Cholesky when 8+ threads spin inside a container."""
+    try:
+        import torch
+    except ImportError:
+        return None, None
+    import os
+    if torch.cuda.is_available() and not os.environ.get("MI355_SETUP_ON_CPU"):
+        return torch, torch.device("cuda")
+    return torch, torch.device("cpu")
+
+
+def local_schur_by_level_elimination(A_II, A_IΓ, A_ΓΓ) -> np.ndarray:
+    """Dense S_d = A_ΓΓ - A_IΓ' A_II^{-1} A_IΓ by exact block elimination.
+
+    The interior is split into breadth-first levels L_0, L_1, ... grown from the interior nodes
+    adjacent to Γ_d; A_II is block tridiagonal in that ordering, so eliminating from the deepest
+    level towards Γ_d is the recursion T_m = A_mm, T_k = A_kk - A_{k+1,k}' T_{k+1}^{-1} A_{k+1,k},
+    and S_d = A_ΓΓ - A_{0Γ}' T_0^{-1} A_{0Γ}. Every step is dense Cholesky + triangular solve +
+    product (BLAS-3), which is far faster than n_Γd sparse triangular solves with 124 k unknowns.
+    """
+    A_II = sp.csr_matrix(A_II)
+    A_IΓ = sp.csr_matrix(A_IΓ)
+    S = np.asarray(sp.csr_matrix(A_ΓΓ).todense(), dtype=np.float64)
+    seeds = np.flatnonzero(np.diff(A_IΓ.indptr) > 0)
+    if seeds.size == 0:
+        return S
+    levels = _bfs_levels_from_interface(A_II, seeds)
+    perm = np.concatenate(levels)
+    off = np.concatenate(([0], np.cumsum([l.size for l in levels])))
+    Ap = sp.csr_matrix(A_II[perm][:, perm])
+    torch, dev = _dense_device()
+
+    def blk(i, j):
+        a = Ap[off[i]:off[i + 1], off[j]:off[j + 1]].toarray()
+        return torch.from_numpy(a).to(dev) if torch is not None else a
+
+    if torch is not None:
+        chol = torch.linalg.cholesky
+        def trsm(c, b):
+            return torch.linalg.solve_triangular(c, b, upper=False)
+    else:
+        import scipy.linalg as sla
+        chol = np.linalg.cholesky
+        def trsm(c, b):
+            return sla.solve_triangular(c, b, lower=True, check_finite=False)
+
+    m = len(levels) - 1
+    T = blk(m, m)
+    for k in range(m - 1, -1, -1):
+        Y = trsm(chol(T), blk(k + 1, k))
+        T = blk(k, k) - Y.T @ Y
+    B = A_IΓ[levels[0]].toarray()
+    Y = trsm(chol(T), torch.from_numpy(B).to(dev) if torch is not None else B)
+    YtY = Y.T @ Y
+    S -= YtY.cpu().numpy() if torch is not None else YtY
+    return S
+
+
+def assemble_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, solvers: Optional[Sequence["InteriorSolver"]] = None,
+                          method: str = "levels", chunk: int = 256):
     """`assemble_local_schurs` (EPDD.jl:667-695): dense S_d = A_ΓΓd - A_IΓd' A_IId^{-1} A_IΓd.
 
-    The reference applies `apply_local_schur` to every unit vector and keeps the upper
-    triangle (`Symmetric(Array(map))`, :692); here the columns come from a multi-RHS
-    direct solve and the result is symmetrised the same way (upper triangle mirrored).
-    Returns column-major (Fortran-order) arrays like Julia's `Array`.
+    The reference applies `apply_local_schur` (interior CG, reltol 1e-9) to every unit vector and
+    keeps the upper triangle (`Symmetric(Array(map))`, :692). Here the blocks come from an exact
+    direct elimination (`method="levels"`, see local_schur_by_level_elimination) or from multi-RHS
+    SuperLU solves (`method="solves"`, slow; kept as the cross-check), and are symmetrised the
+    same way. Returns column-major (Fortran-order) arrays like Julia's `Array`.
     """
     out = []
     for d in range(len(A_IIdd)):
         n = A_ΓΓdd[d].shape[0]
-        solve = solvers[d] if solvers is not None else InteriorSolver(A_IIdd[d])
-        S = np.asarray(A_ΓΓdd[d].todense(), dtype=np.float64)
-        AIΓ = sp.csc_matrix(A_IΓdd[d])
-        AΓI = sp.csr_matrix(A_IΓdd[d].T)
-        for c0 in range(0, n, chunk):
-            c1 = min(n, c0 + chunk)
-            V = solve(AIΓ[:, c0:c1].toarray())
-            S[:, c0:c1] -= AΓI @ V
+        if method == "levels":
+            S = local_schur_by_level_elimination(A_IIdd[d], A_IΓdd[d], A_ΓΓdd[d])
+        else:
+            solve = solvers[d] if solvers is not None else InteriorSolver(A_IIdd[d])
+            S = np.asarray(A_ΓΓdd[d].todense(), dtype=np.float64)
+            AIΓ = sp.csc_matrix(A_IΓdd[d])
+            AΓI = sp.csr_matrix(A_IΓdd[d].T)
+            for c0 in range(0, n, chunk):
+                c1 = min(n, c0 + chunk)
+                V = solve(AIΓ[:, c0:c1].toarray())
+                S[:, c0:c1] -= AΓI @ V
         S = np.triu(S) + np.triu(S, 1).T
         out.append(np.asfortranarray(S))
     return out
@@ -565,22 +651,33 @@ class SchurProblem:
 
 
 def build_schur_problem(N: int, px: int, py: int, coeff: Coeff, f, uexact,
-                        assemble: bool = True, precond: bool = True) -> SchurProblem:
+                        assemble: bool = True, precond: bool = True, dom_slice=None) -> SchurProblem:
     """Example03:45-150 set-up flow on the synthetic mesh (mesh → partition → maps →
-    local blocks → b_schur → assembled S_d → Neumann-Neumann pseudo-inverses)."""
+    local blocks → b_schur → assembled S_d → Neumann-Neumann pseudo-inverses).
+
+    `dom_slice=(lo, hi)` (multi-GPU: one call per rank) factorises, assembles and pseudo-inverts
+    only subdomains lo..hi-1; the other entries of `solvers`, `Sd`, `ΠSd` are None and
+    `b_schur` then holds only this rank's share  -Σ_{d in slice} R_d' A_IΓd' A_IId^{-1} b_Id
+    (+ b_Γ on the rank that owns subdomain 0), so that the sum over ranks is the full b_schur.
+    """
     mesh = get_mesh(N)
     dinds = get_dirichlet_inds(mesh.points, mesh.point_marker)
     epart, npart = mesh_partition(mesh, px, py)
     sub = set_subdomains(mesh.cells, mesh.cell_neighbors, epart, npart, dinds.dirichlet_g2l)
-    if callable(coeff) and getattr(coeff, "_wants_points", False):
-        coeff = coeff(mesh.points)
     A_II, A_IΓ, A_ΓΓ, b_Id, b_Γ = prepare_local_schurs(mesh.cells, mesh.points, epart, sub, coeff, f, uexact)
-    solvers = [InteriorSolver(A) for A in A_II]
-    b_schur = get_schur_rhs(b_Id, A_II, A_IΓ, b_Γ, sub.gather_idx, solvers)
+    lo, hi = (0, sub.ndom) if dom_slice is None else dom_slice
+    solvers = [InteriorSolver(A_II[d]) if lo <= d < hi else None for d in range(sub.ndom)]
+    b_schur = np.array(b_Γ, copy=True) if lo == 0 else np.zeros_like(b_Γ)
+    for d in range(lo, hi):                 # get_schur_rhs (EPDD.jl:835-864), this rank's subdomains
+        b_schur[sub.gather_idx[d]] -= A_IΓ[d].T @ solvers[d](b_Id[d])
     prob = SchurProblem(mesh, dinds, sub, epart, A_II, A_IΓ, A_ΓΓ, b_Id, b_Γ, b_schur,
                         solvers=solvers, uexact=uexact)
+    prob.info["dom_slice"] = (lo, hi)
     if assemble:
-        prob.Sd = assemble_local_schurs(A_II, A_IΓ, A_ΓΓ, solvers)
+        loc = range(lo, hi)
+        Sd = assemble_local_schurs([A_II[d] for d in loc], [A_IΓ[d] for d in loc], [A_ΓΓ[d] for d in loc])
+        prob.Sd = [Sd[d - lo] if lo <= d < hi else None for d in range(sub.ndom)]
         if precond:
-            prob.ΠSd = prepare_neumann_neumann_schur_precond(prob.Sd)
+            Pi = prepare_neumann_neumann_schur_precond(Sd)
+            prob.ΠSd = [Pi[d - lo] if lo <= d < hi else None for d in range(sub.ndom)]
     return prob

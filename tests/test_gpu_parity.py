@@ -1,0 +1,270 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+inputs and against the committed golden fixtures.
+
+Tolerances (all arithmetic fp64):
+  * element-wise kernels (axpy, axpby) and the CSR SpMV: BIT-EXACT vs the oracle (same operation
+    order, library built with -ffp-contract=off);
+  * reductions (dot, dense GEMV rows) reorder sums: rel. 1e-13 on a single apply;
+  * solvers: `it` equal; res_norm entries rel. diff <= 1e-8; solution rel. l2 diff <= 1e-6.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import GOLDEN, a_example01, f_m1, lognormal_coeff, lowest_eigvecs, u0734, u3
+
+pytestmark = pytest.mark.gpu
+
+RES_RTOL = 1e-8
+X_RTOL = 1e-6
+
+
+def assert_history(got, want):
+    x, it, res = got
+    xo, ito, reso = want
+    assert it == ito, f"iteration counts differ: {it} vs oracle {ito}"
+    assert res.shape == reso.shape
+    assert np.allclose(res, reso, rtol=RES_RTOL, atol=0.0), np.max(np.abs(res - reso) / reso)
+    assert np.linalg.norm(x - xo) <= X_RTOL * np.linalg.norm(xo)
+
+
+def gpu_ops(pkg, ctx, P):
+    api = pkg.api
+    return (api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt),
+            api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt))
+
+
+def orc_ops(orc, P):
+    return (orc.apply_local_schurs_operator(P.Sd, P.sub.gather_idx, P.sub.n_Γ),
+            orc.neumann_neumann_operator(P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt))
+
+
+# ------------------------------------------------------------------ BLAS-1
+@pytest.mark.parametrize("n", [1, 63, 64, 1000, 3989, 248004])
+def test_blas1(ctx, n):
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    assert np.isclose(ctx.dot(x, y), np.dot(x, y), rtol=1e-12, atol=1e-12 * np.sqrt(n))
+    assert np.isclose(ctx.norm2(x), np.linalg.norm(x), rtol=1e-13)
+    a, b = 0.37, -1.25
+    assert np.array_equal(ctx.axpy(a, x, y.copy()), y + a * x)            # bit-exact, no FMA
+    assert np.array_equal(ctx.axpby(a, x, b, y.copy()), a * x + b * y)
+
+
+# ------------------------------------------------------------------ CSR SpMV: bit-exact
+def test_spmv_bit_exact_vs_oracle(pkg, ctx, orc, fem, toy):
+    mesh = fem.get_mesh(120)
+    d = fem.get_dirichlet_inds(mesh.points, mesh.point_marker)
+    A, b = fem.do_isotropic_elliptic_assembly(mesh.cells, mesh.points, d, mesh.point_marker, a_example01, f_m1, u3)
+    rng = np.random.default_rng(5)
+    for M in (A, toy.A_IIdd[1], sp.identity(5, format="csr"), sp.csr_matrix((7, 7))):
+        n = M.shape[0]
+        x = rng.standard_normal(n)
+        got = pkg.api.SparseMatrixCSC(ctx, M) * x
+        want = orc.csc_operator(M) * x          # stdlib CSC scatter order
+        assert np.array_equal(got, want)
+
+
+def test_spmv_long_row_and_one_based(pkg, ctx, orc):
+    # an arrow matrix: row/column 0 is dense with n > SPMV_TILE entries (the single-long-row path)
+    n = 5000
+    rng = np.random.default_rng(6)
+    v = rng.standard_normal(n)
+    A = sp.lil_matrix((n, n))
+    A[0, :] = v
+    A[:, 0] = v.reshape(-1, 1)
+    A.setdiag(np.abs(v) + n)
+    A = sp.csr_matrix(A)
+    x = rng.standard_normal(n)
+    want = orc.csc_operator(A) * x
+    assert np.array_equal(pkg.api.SparseMatrixCSC(ctx, A) * x, want)
+    # Julia-style 1-based arrays through index_base=1
+    A.sort_indices()
+    op1 = pkg.api.SparseMatrixCSC(ctx, (A.indptr + 1, A.indices + 1, A.data, n), index_base=1)
+    assert np.array_equal(op1 * x, want)
+
+
+# ------------------------------------------------------------------ Schur / NN applies
+@pytest.mark.parametrize("case", ["micro", "toy", "ragged"])
+def test_assembled_applies_vs_oracle(pkg, ctx, orc, case, micro, toy, ragged):
+    P = {"micro": micro, "toy": toy, "ragged": ragged}[case]
+    S, M = gpu_ops(pkg, ctx, P)
+    So, Mo = orc_ops(orc, P)
+    rng = np.random.default_rng(8)
+    for _ in range(2):
+        v = rng.standard_normal(P.sub.n_Γ)
+        ys, yo = S * v, So * v
+        assert np.allclose(ys, yo, rtol=0, atol=1e-13 * np.abs(yo).max())
+        zs, zo = M.ldiv(v), Mo * v
+        assert np.allclose(zs, zo, rtol=0, atol=1e-13 * np.abs(zo).max())
+    # reference-named free functions
+    assert np.array_equal(pkg.api.apply_local_schurs(S, v), ys)
+    assert np.array_equal(pkg.api.apply_neumann_neumann_schur(M, v), zs)
+
+
+def test_applies_vs_golden(pkg, ctx):
+    for name in ("micro", "toy"):
+        G = np.load(f"{GOLDEN}/{name}.npz")
+        nd = 4
+        Sd = [G[f"Sd_{d}"] for d in range(nd)]
+        Pi = [G[f"PiSd_{d}"] for d in range(nd)]
+        gi = [G[f"gather_idx_{d}"] for d in range(nd)]
+        S = pkg.api.LocalSchurs(ctx, Sd, gi, G["node_gamma_cnt"])
+        M = pkg.api.NeumannNeumannSchurPreconditioner(ctx, Pi, gi, G["node_gamma_cnt"])
+        assert np.allclose(S * G["v"], G["S_v"], rtol=0, atol=1e-13 * np.abs(G["S_v"]).max())
+        assert np.allclose(M.ldiv(G["v"]), G["M_v"], rtol=0, atol=1e-13 * np.abs(G["M_v"]).max())
+        b, x0 = G["b_schur"], np.zeros(int(G["n_gamma"]))
+        for tag, got in (("cg", pkg.api.cg(S, b, x0)), ("pcg", pkg.api.pcg(S, b, x0, M)),
+                         ("defpcg", pkg.api.defpcg(S, b, x0, G["W"], M))):
+            assert_history(got, (G[f"{tag}_x"], int(G[f"{tag}_it"]), G[f"{tag}_res_norm"]))
+
+
+def test_domain_slices_sum_to_full_apply(pkg, ctx, ragged):
+    """A rank's operator applies only its slice of subdomains; the slices add up to the full sum
+    (what the RCCL all-reduce computes across GPUs)."""
+    P = ragged
+    rng = np.random.default_rng(9)
+    v = rng.standard_normal(P.sub.n_Γ)
+    full = pkg.api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt) * v
+    acc = np.zeros_like(full)
+    for lo, hi in ((0, 2), (2, 2), (2, 5), (5, 6)):                     # includes an empty slice
+        acc += pkg.api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(lo, hi)) * v
+    assert np.allclose(acc, full, rtol=0, atol=1e-13 * np.abs(full).max())
+
+
+def test_matrix_free_and_global_schur_vs_oracle(pkg, ctx, orc, fem, ragged):
+    P = ragged
+    n = P.sub.n_Γ
+    Sm = pkg.api.MatrixFreeLocalSchurs(ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, P.sub.node_Γ_cnt, P.solvers)
+    Smo = orc.apply_local_schurs_matfree_operator(P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, n, P.solvers)
+    rng = np.random.default_rng(10)
+    v = rng.standard_normal(n)
+    want = Smo * v
+    got = Sm * v
+    # sparse products are bit-exact; the interior solve is the same host callback
+    assert np.array_equal(got, want)
+    coeff = lognormal_coeff(fem, P.mesh.points, 7)
+    A_IIg, A_IΓg, A_ΓΓ, b_Id, b_Γ = fem.prepare_global_schur(P.mesh.cells, P.mesh.points, P.epart, P.sub, coeff, f_m1, u0734)
+    Sg = pkg.api.GlobalSchur(ctx, A_IIg, A_IΓg, A_ΓΓ, P.solvers)
+    Sgo = orc.apply_global_schur_operator(A_IIg, A_IΓg, A_ΓΓ, P.solvers)
+    assert np.array_equal(pkg.api.apply_global_schur(Sg, v), Sgo * v)
+    # Example03:175 identity on the device path
+    Sa = pkg.api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+    assert np.allclose(Sa * v, got, rtol=0, atol=1e-11 * np.abs(got).max())
+    # pcg on the matrix-free operator (eager loop, host callback every apply)
+    M = pkg.api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+    Mo = orc.neumann_neumann_operator(P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+    assert_history(pkg.api.pcg(Sm, P.b_schur, np.zeros(n), M), orc.pcg(Smo, P.b_schur, np.zeros(n), Mo))
+
+
+# ------------------------------------------------------------------ solvers
+@pytest.mark.parametrize("case", ["micro", "toy", "ragged"])
+def test_schur_solvers_vs_oracle(pkg, ctx, orc, case, micro, toy, ragged):
+    P = {"micro": micro, "toy": toy, "ragged": ragged}[case]
+    api = pkg.api
+    S, M = gpu_ops(pkg, ctx, P)
+    So, Mo = orc_ops(orc, P)
+    n, b = P.sub.n_Γ, P.b_schur
+    x0 = np.zeros(n)
+    assert_history(api.cg(S, b, x0), orc.cg(So, b, x0))
+    assert_history(api.pcg(S, b, x0, M), orc.pcg(So, b, x0, Mo))
+    W = lowest_eigvecs(So, n, P.sub.ndom + 10)                            # Example03:206
+    assert_history(api.defcg(S, b, x0, W), orc.defcg(So, b, x0, W))
+    assert_history(api.defpcg(S, b, x0, W, M), orc.defpcg(So, b, x0, W, Mo))
+    # non-zero initial guess
+    x1 = np.random.default_rng(11).standard_normal(n)
+    assert_history(api.pcg(S, b, x1, M), orc.pcg(So, b, x1, Mo))
+    assert_history(api.defpcg(S, b, x1, W, M), orc.defpcg(So, b, x1, W, Mo))
+
+
+def test_full_system_pcg_config2_small(pkg, ctx, orc, fem):
+    """Example01 flow (config 2) at N=150: CSR SpMV + BLAS-1 kernels only, multi-workgroup reductions."""
+    mesh = fem.get_mesh(150)
+    d = fem.get_dirichlet_inds(mesh.points, mesh.point_marker)
+    A, b = fem.do_isotropic_elliptic_assembly(mesh.cells, mesh.points, d, mesh.point_marker, a_example01, f_m1, u3)
+    n = b.size
+    api = pkg.api
+    Ag, Ao = api.SparseMatrixCSC(ctx, A), orc.csc_operator(A)
+    x0 = np.zeros(n)
+    assert_history(api.cg(Ag, b, x0), orc.cg(Ao, b, x0))
+    assert_history(api.pcg(Ag, b, x0, api.JacobiPreconditioner(ctx, A.diagonal())),
+                   orc.pcg(Ao, b, x0, orc.jacobi_operator(A.diagonal())))
+    assert_history(api.pcg(Ag, b, x0, api.IdentityPreconditioner(ctx, n)),
+                   orc.pcg(Ao, b, x0, orc.identity_operator(n)))
+
+
+def test_stop_rule_edges(pkg, ctx, orc, micro):
+    P = micro
+    api = pkg.api
+    S, M = gpu_ops(pkg, ctx, P)
+    So, Mo = orc_ops(orc, P)
+    n, b = P.sub.n_Γ, P.b_schur
+    x0 = np.zeros(n)
+    for maxit in (1, 2, 3, 7):
+        assert_history(api.pcg(S, b, x0, M, maxit=maxit), orc.pcg(So, b, x0, Mo, maxit=maxit))
+        assert_history(api.cg(S, b, x0, maxit=maxit), orc.cg(So, b, x0, maxit=maxit))
+    xs, its, _ = orc.pcg(So, b, x0, Mo)
+    x, it, res = api.pcg(S, b, xs, M)                                     # converged initial guess: no loop pass
+    assert it == 1 and res.size == 1
+    x, it, res = api.cg(S, np.zeros(n), x0)                               # b = 0: tol = 0, res = 0 -> it = 1
+    assert it == 1 and res[0] == 0.0 and not np.any(x)
+    assert_history(api.pcg(S, b, x0, M, eps=1e-12), orc.pcg(So, b, x0, Mo, eps=1e-12))
+
+
+def test_results_do_not_depend_on_chunking_or_pointer_mode(pkg, ctx, toy):
+    import torch
+    api = pkg.api
+    P = toy
+    S, M = gpu_ops(pkg, ctx, P)
+    n, b = P.sub.n_Γ, P.b_schur
+    ref = None
+    try:
+        for chunk in (0, 1, 5, 8, 64):
+            ctx.set_chunk(chunk)
+            got = api.pcg(S, b, np.zeros(n), M)
+            if ref is None:
+                ref = got
+            assert got[1] == ref[1] and np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0])
+    finally:
+        ctx.set_chunk(8)
+    bt = torch.from_numpy(b).cuda()
+    xt = torch.zeros(n, dtype=torch.float64, device="cuda")
+    x, it, res = api.pcg(S, bt, xt, M)
+    assert x is xt and it == ref[1] and np.array_equal(res, ref[2])       # x mutated in place, like the reference
+    assert np.array_equal(xt.cpu().numpy(), ref[0])
+    yt = S * bt
+    assert np.array_equal(yt.cpu().numpy(), S * b)
+
+
+def test_error_conventions(pkg, ctx, toy):
+    api = pkg.api
+    P = toy
+    S, M = gpu_ops(pkg, ctx, P)
+    n, b = P.sub.n_Γ, P.b_schur
+    W = np.asfortranarray(np.column_stack([b, b]))                        # rank-deficient W
+    with pytest.raises(api.SingularException):
+        api.defpcg(S, b, np.zeros(n), W, M)
+    x, it, res = api.pcg(S, b, np.zeros(n), M)                            # the context is still usable
+    assert it > 1
+    with pytest.raises(ValueError):
+        api.pcg(S, b[:-1], np.zeros(n), M)
+    with pytest.raises(api.MiError):                                      # gather index out of range
+        api.LocalSchurs(ctx, P.Sd, [g + 10**6 for g in P.sub.gather_idx], P.sub.node_Γ_cnt)
+    with pytest.raises(api.MiError):                                      # repeated Γ index in one subdomain
+        bad = [g.copy() for g in P.sub.gather_idx]
+        bad[0][1] = bad[0][0]
+        api.LocalSchurs(ctx, P.Sd, bad, P.sub.node_Γ_cnt)
+
+
+def test_rccl_single_rank_communicator(pkg, ctx, orc, micro):
+    """world_size 1 on the one GPU of the box: the RCCL binding, communicator set-up and an
+    all-reduce captured inside the iteration graph all execute; the result must not change."""
+    api = pkg.api
+    P = micro
+    c2 = api.Context(0)
+    c2.comm_init(c2.unique_id(), 0, 1)
+    v = np.arange(5, dtype=np.float64)
+    assert np.array_equal(c2.allreduce_sum(v.copy()), v)
+    S, M = gpu_ops(pkg, c2, P)
+    So, Mo = orc_ops(orc, P)
+    assert_history(api.pcg(S, P.b_schur, np.zeros(P.sub.n_Γ), M), orc.pcg(So, P.b_schur, np.zeros(P.sub.n_Γ), Mo))

@@ -1,0 +1,235 @@
+"""CPU suite (-m "not gpu"): pins the oracle and the host-side set-up.
+
+The reference ships no tests or golden vectors for this path, so the oracle is
+pinned by (1) agreement of the C restatement with independent numpy expressions, (2) the identities
+the reference prints at run time (Example03:175 and :204), (3) known-answer tests, and (4) the
+committed fixtures in tests/golden/ (made by tests/golden/make_golden.py from this same oracle —
+a regression pin, not an external one: PARITY UNPINNED against Julia itself).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from conftest import GOLDEN, a_example01, f_m1, lowest_eigvecs, one, u0734, u3
+
+
+# ------------------------------------------------------------------ C restatement vs numpy
+def test_blas1_and_spmv_match_numpy(orc, toy):
+    rng = np.random.default_rng(0)
+    A = sp.csc_matrix(toy.A_IIdd[0])
+    x = rng.standard_normal(A.shape[0])
+    op = orc.csc_operator(A)
+    opg = orc.csc_operator(A, gather=True)
+    y = op(x)
+    assert np.array_equal(y, opg(x))            # scatter (CSC) and gather (CSR) orders agree on symmetric A
+    assert np.allclose(y, A @ x, rtol=1e-13, atol=1e-13)
+    # left-to-right row sums, no FMA: reproduce with a python loop on a few rows
+    Ar = sp.csr_matrix(A)
+    for i in (0, 17, A.shape[0] - 1):
+        s = 0.0
+        for k in range(Ar.indptr[i], Ar.indptr[i + 1]):
+            s += Ar.data[k] * x[Ar.indices[k]]
+        assert s == y[i]
+
+
+def test_lu_solve_matches_numpy(orc):
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((14, 14))
+    b = rng.standard_normal(14)
+    assert np.allclose(orc.lu_solve(A, b), np.linalg.solve(A, b), rtol=1e-10)
+    with pytest.raises(orc.SingularException):
+        orc.lu_solve(np.zeros((3, 3)), np.ones(3))
+
+
+def test_assembled_and_nn_apply_match_numpy(orc, ragged):
+    P = ragged
+    n = P.sub.n_Γ
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(n)
+    S = orc.apply_local_schurs_operator(P.Sd, P.sub.gather_idx, n)
+    M = orc.neumann_neumann_operator(P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+    ys, ym = np.zeros(n), np.zeros(n)
+    cnt = P.sub.node_Γ_cnt.astype(float)
+    for d in range(P.sub.ndom):
+        g = P.sub.gather_idx[d]
+        ys[g] += P.Sd[d] @ x[g]
+        ym[g] += (P.ΠSd[d] @ (x[g] / cnt[g])) / cnt[g]
+    assert np.allclose(S(x), ys, rtol=1e-12, atol=1e-12)
+    assert np.allclose(M(x), ym, rtol=1e-12, atol=1e-12)
+
+
+# ------------------------------------------------------------------ set-up facts (SURVEY.md §8 sizes)
+def test_toy_sizes_and_maps(toy):
+    s = toy.sub
+    assert s.n_Γ == 195 and sorted(s.n_Γd) == [97, 98, 98, 99]
+    assert sum(s.n_Id) + s.n_Γ == 98 * 98 == 9604
+    assert set(np.unique(s.node_Γ_cnt)) == {2, 4} and (s.node_Γ_cnt == 4).sum() == 1
+    for d in range(s.ndom):
+        assert np.array_equal(s.node_Γ[s.gather_idx[d]], s.node_Γd[d])
+        assert len(set(s.gather_idx[d])) == s.n_Γd[d]
+    assert np.array_equal(np.bincount(np.concatenate(s.gather_idx), minlength=s.n_Γ), s.node_Γ_cnt)
+
+
+def test_blocks_are_symmetric_and_consistent_with_full_matrix(fem, toy):
+    P = toy
+    A, b = fem.do_isotropic_elliptic_assembly(P.mesh.cells, P.mesh.points, P.dinds, P.mesh.point_marker, one, f_m1, u0734)
+    assert abs(A - A.T).max() == 0.0           # bitwise symmetric (EPDD.jl:294 ΔKij is symmetric in i,j)
+    for d in range(P.sub.ndom):
+        assert abs(P.A_IIdd[d] - P.A_IIdd[d].T).max() == 0.0
+        assert abs(P.A_ΓΓdd[d] - P.A_ΓΓdd[d].T).max() == 0.0
+        # interior block of the full matrix == A_II of the subdomain
+        rows = P.dinds.not_dirichlet_g2l[P.sub.node_Id[d]]
+        assert abs(A[rows][:, rows] - P.A_IIdd[d]).max() < 1e-14
+
+
+# ------------------------------------------------------------------ identities the reference prints
+def test_three_schur_formulations_agree(fem, orc, ragged):
+    """Example03:175 `extrema(S_global*b_schur - S_local_mat*b_schur)`; exact to rounding with a direct interior solve."""
+    P = ragged
+    mesh = P.mesh
+    coeff = P.info.get("coeff")
+    n = P.sub.n_Γ
+    Sa = orc.apply_local_schurs_operator(P.Sd, P.sub.gather_idx, n)
+    Sm = orc.apply_local_schurs_matfree_operator(P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, n, P.solvers)
+    v = P.b_schur
+    assert np.allclose(Sa(v), Sm(v), rtol=1e-11, atol=1e-12 * np.abs(Sa(v)).max())
+
+
+def test_schur_solution_matches_direct_solve(fem, orc, toy):
+    """Example03:193-204: NN-PCG on S, back-substitute, merge; compare with the full-system solve."""
+    P = toy
+    n = P.sub.n_Γ
+    S = orc.apply_local_schurs_operator(P.Sd, P.sub.gather_idx, n)
+    M = orc.neumann_neumann_operator(P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+    uΓ, it, res = orc.pcg(S, P.b_schur, np.zeros(n), M)
+    assert it < 20 and res[-1] <= 1e-7 * np.linalg.norm(P.b_schur)
+    A_IIg, A_IΓg, A_ΓΓ, b_Id, b_Γ = fem.prepare_global_schur(P.mesh.cells, P.mesh.points, P.epart, P.sub, one, f_m1, u0734)
+    Sg = orc.apply_global_schur_operator(A_IIg, A_IΓg, A_ΓΓ, P.solvers)
+    assert np.allclose(Sg(P.b_schur), S(P.b_schur), rtol=1e-11, atol=1e-13)
+    u_dd = fem.merge_subdomain_solutions(uΓ, fem.get_subdomain_solutions(uΓ, A_IIg, A_IΓg, b_Id, P.solvers),
+                                         P.sub, P.dinds, u0734, P.mesh.points)
+    A, b = fem.do_isotropic_elliptic_assembly(P.mesh.cells, P.mesh.points, P.dinds, P.mesh.point_marker, one, f_m1, u0734)
+    u = fem.append_bc(P.dinds, spla.spsolve(sp.csc_matrix(A), b), P.mesh.points, u0734)
+    assert np.abs(u_dd - u).max() < 1e-8
+
+
+# ------------------------------------------------------------------ known answers
+def test_constant_and_affine_solutions_are_exact(fem, orc):
+    """P1 reproduces affine functions: f = 0, u = uexact on the boundary => nodal solution exact."""
+    zero = lambda x, y: 0.0 * x
+    for uex in (u0734, lambda x, y: 2.0 * x - 3.0 * y + 0.5):
+        P = fem.build_schur_problem(30, 3, 2, one, zero, uex)
+        n = P.sub.n_Γ
+        S = orc.apply_local_schurs_operator(P.Sd, P.sub.gather_idx, n)
+        M = orc.neumann_neumann_operator(P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+        uΓ, it, _ = orc.pcg(S, P.b_schur, np.zeros(n), M)
+        pts = P.mesh.points[:, P.sub.node_Γ]
+        assert np.abs(uΓ - uex(pts[0], pts[1])).max() < 1e-6
+
+
+def test_floating_subdomain_schur_is_singular_with_constant_kernel(fem):
+    """S_d * 1 = 0 on a subdomain that touches no Dirichlet node; pinv drops exactly that mode."""
+    P = fem.build_schur_problem(31, 3, 3, one, f_m1, u0734)
+    d = 4                                                  # the centre box
+    assert P.dinds.dirichlet_g2l[P.mesh.cells[:, P.sub.elemd[d]]].max() == -1
+    S = P.Sd[d]
+    assert np.abs(S @ np.ones(S.shape[0])).max() < 1e-10 * np.abs(S).max()
+    assert np.linalg.matrix_rank(P.ΠSd[d], tol=1e-8) == S.shape[0] - 1
+    assert np.abs(S - S.T).max() == 0.0                    # `Symmetric(...)`, EPDD.jl:692
+
+
+def test_operator_symmetry_and_nn_semidefinite(orc, ragged):
+    P = ragged
+    n = P.sub.n_Γ
+    rng = np.random.default_rng(3)
+    v, w = rng.standard_normal(n), rng.standard_normal(n)
+    S = orc.apply_local_schurs_operator(P.Sd, P.sub.gather_idx, n)
+    M = orc.neumann_neumann_operator(P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+    assert abs(v @ S(w) - w @ S(v)) < 1e-10 * abs(v @ S(w))
+    assert abs(v @ M(w) - w @ M(v)) < 1e-8 * max(1.0, abs(v @ M(w)))
+    assert v @ S(v) > 0 and v @ M(v) >= -1e-12
+
+
+def test_cg_semantics(orc, micro):
+    P = micro
+    n = P.sub.n_Γ
+    S = orc.apply_local_schurs_operator(P.Sd, P.sub.gather_idx, n)
+    b = P.b_schur
+    x, it, res = orc.cg(S, b, np.zeros(n))
+    assert it <= n and res.size == it                      # SPD n x n: at most n iterations; res_norm[1:it]
+    assert res[0] == np.sqrt(np.dot(b, b)) or np.isclose(res[0], np.linalg.norm(b), rtol=1e-15)
+    assert res[-1] <= 1e-7 * np.linalg.norm(b) < res[-2]   # stops at the first entry under tol
+    # maxit: `while it < maxit` => exactly maxit entries, maxit-1 loop passes (cg.jl:34)
+    x3, it3, res3 = orc.cg(S, b, np.zeros(n), maxit=3)
+    assert it3 == 3 and np.array_equal(res3, res[:3])
+    # exact initial guess: it = 1, no loop pass
+    x1, it1, res1 = orc.cg(S, b, x)
+    assert it1 == 1 and res1[0] <= 1e-7 * np.linalg.norm(b)
+
+
+def test_deflation_semantics(orc, toy):
+    P = toy
+    n = P.sub.n_Γ
+    S = orc.apply_local_schurs_operator(P.Sd, P.sub.gather_idx, n)
+    M = orc.neumann_neumann_operator(P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+    b, x0 = P.b_schur, np.zeros(n)
+    xp, itp, resp = orc.pcg(S, b, x0, M)
+    # W with zero columns: defpcg == pcg, defcg == cg, entry for entry
+    W0 = np.zeros((n, 0), order="F")
+    xd, itd, resd = orc.defpcg(S, b, x0, W0, M)
+    assert itd == itp and np.array_equal(resd, resp) and np.array_equal(xd, xp)
+    xc, itc, resc = orc.cg(S, b, x0)
+    xdc, itdc, resdc = orc.defcg(S, b, x0, W0)
+    assert itdc == itc and np.array_equal(resdc, resc)
+    # deflating the nev lowest eigenvectors (Example03:206-214, nev = ndom + 10) cannot slow CG down
+    W = lowest_eigvecs(S, n, P.sub.ndom + 10)
+    xw, itw, _ = orc.defcg(S, b, x0, W)
+    assert itw < itc and np.linalg.norm(xw - xc) < 1e-5 * np.linalg.norm(xc)
+    xq, itq, _ = orc.defpcg(S, b, x0, W, M)
+    assert itq <= itp and np.linalg.norm(xq - xp) < 1e-5 * np.linalg.norm(xp)
+    # rank-deficient W => SingularException from `WtAW \ mu` (README "To do")
+    Wbad = np.asfortranarray(np.column_stack([W[:, 0], W[:, 0]]))
+    with pytest.raises(orc.SingularException):
+        orc.defpcg(S, b, x0, Wbad, M)
+
+
+def test_full_system_pcg_config2_shape(fem, orc):
+    """Example01 flow at a small N: full A, pcg with Jacobi / none standing in for AMG."""
+    mesh = fem.get_mesh(40)
+    d = fem.get_dirichlet_inds(mesh.points, mesh.point_marker)
+    A, b = fem.do_isotropic_elliptic_assembly(mesh.cells, mesh.points, d, mesh.point_marker, a_example01, f_m1, u3)
+    Aop = orc.csc_operator(A)
+    x, it, res = orc.pcg(Aop, b, np.zeros(b.size), orc.jacobi_operator(A.diagonal()))
+    xi, iti, resi = orc.pcg(Aop, b, np.zeros(b.size), orc.identity_operator(b.size))
+    xc, itc, resc = orc.cg(Aop, b, np.zeros(b.size))
+    assert iti == itc and np.array_equal(resi, resc)       # M = I: pcg == cg entry for entry
+    u = spla.spsolve(sp.csc_matrix(A), b)
+    assert np.linalg.norm(x - u) < 1e-5 * np.linalg.norm(u)
+
+
+# ------------------------------------------------------------------ golden fixtures
+@pytest.mark.parametrize("name", ["micro", "toy"])
+def test_oracle_reproduces_golden(orc, fem, name, micro, toy):
+    P = {"micro": micro, "toy": toy}[name]
+    G = np.load(f"{GOLDEN}/{name}.npz")
+    n = P.sub.n_Γ
+    assert int(G["n_gamma"]) == n
+    assert np.array_equal(G["node_gamma_cnt"], P.sub.node_Γ_cnt)
+    for d in range(P.sub.ndom):
+        assert np.array_equal(G[f"gather_idx_{d}"], P.sub.gather_idx[d])
+        assert np.allclose(G[f"Sd_{d}"], P.Sd[d], rtol=1e-9, atol=1e-12)   # SuperLU pivot order may vary
+    assert np.allclose(G["b_schur"], P.b_schur, rtol=1e-10)
+    # solver histories from the STORED blocks are reproduced exactly by the oracle
+    Sd = [G[f"Sd_{d}"] for d in range(P.sub.ndom)]
+    Pi = [G[f"PiSd_{d}"] for d in range(P.sub.ndom)]
+    gi = [G[f"gather_idx_{d}"] for d in range(P.sub.ndom)]
+    S = orc.apply_local_schurs_operator(Sd, gi, n)
+    M = orc.neumann_neumann_operator(Pi, gi, G["node_gamma_cnt"])
+    b, x0 = G["b_schur"], np.zeros(n)
+    for tag, run in (("cg", lambda: orc.cg(S, b, x0)), ("pcg", lambda: orc.pcg(S, b, x0, M)),
+                     ("defpcg", lambda: orc.defpcg(S, b, x0, G["W"], M))):
+        x, it, res = run()
+        assert it == int(G[f"{tag}_it"])
+        assert np.array_equal(res, G[f"{tag}_res_norm"])
+        assert np.array_equal(x, G[f"{tag}_x"])

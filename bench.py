@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Neumann-Neumann Schur-PCG on the 1 M-DoF / 8-subdomain problem
+(BASELINE.json configs[2] at N=1; configs[3] sharding at N>1).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one complete `pcg(S, b_schur, 0, ΠSnn)` solve (Example03:193) with the assembled
+local Schur complements resident in HBM. `value` = PCG loop iterations per second over the whole
+job (every iteration = one S-apply + one NN-apply + the BLAS-1 updates; `it` of the reference
+counts from 1, so a solve that returns `it` ran it-1 iterations). Inputs (S_d, ΠS_d, b_schur) are on the
+device before the timed region starts; the timed region is K solves bracketed by barrier + sync.
+
+At N>1 the 8 subdomains are split across ranks (8/N each), Γ-vectors are replicated and the two
+Γ-sums of every iteration are RCCL all-reduces captured inside the iteration graph; total work is
+fixed, so scaling is "strong".
+
+Extra objects on the JSON line: `roofline` for the dominant kernel (batched dense GEMV of the S-apply,
+HIP events on the library's stream) and `cpu_baseline` (the C oracle, OpenMP over the host cores,
+rank 0 at N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--N", type=int, default=1000, help="nodes per side (1000 -> 996 004 free DoF)")
+    ap.add_argument("--px", type=int, default=4)
+    ap.add_argument("--py", type=int, default=2)
+    ap.add_argument("--seed", type=int, default=481456)
+    ap.add_argument("--chunk", type=int, default=-1, help="iterations per captured graph (-1: library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=200)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = graft.load_package()
+    fem, api = pkg.fem, pkg.api
+    ndom = args.px * args.py
+    lo, hi = api.shard_domains(ndom, rank, world)
+
+    # ---------------- problem set-up on the host (not timed; the reference does this in Julia)
+    t0 = time.time()
+    mesh = fem.get_mesh(args.N)
+    kl = fem.synthetic_kl(mesh.points)
+    _, g = fem.draw(kl, np.random.default_rng(args.seed))       # config 3: a = exp(g)
+    coeff = np.exp(g)
+    f = lambda x, y: -1.0 + 0 * x
+    uex = lambda x, y: 0.734 + 0 * x
+    P = fem.build_schur_problem(args.N, args.px, args.py, coeff, f, uex, dom_slice=(lo, hi))
+    n_Γ = P.sub.n_Γ
+    n_free = int((mesh.point_marker == 0).sum())
+    log(rank, f"set-up {time.time() - t0:.1f}s: free DoF={n_free} n_Γ={n_Γ} n_Γd={P.sub.n_Γd} local subdomains {lo}..{hi - 1}")
+
+    # ---------------- device residents
+    ctx = api.Context(local_rank)
+    if args.chunk >= 0:
+        ctx.set_chunk(args.chunk)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(ctx.unique_id()), dtype=torch.uint8).cuda()
+        dist.broadcast(uid, 0)
+        ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        bs = torch.from_numpy(P.b_schur).cuda()
+        dist.all_reduce(bs)                                     # b_schur = Σ_ranks (set-up plumbing)
+        b_host = bs.cpu().numpy()
+    else:
+        b_host = P.b_schur
+    S = api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(lo, hi))
+    M = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(lo, hi))
+    b_dev = torch.from_numpy(b_host).cuda()
+    xs = [torch.zeros(n_Γ, dtype=torch.float64, device="cuda") for _ in range(args.warmup + args.steps)]
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    # ---------------- warm-up, then the timed region: EXACTLY K solves
+    its = None
+    for w in range(args.warmup):
+        _, it, res = api.pcg(S, b_dev, xs[w], M)
+        its = it if its is None else its
+        assert it == its
+    if its is None:
+        _, its, res = api.pcg(S, b_dev, torch.zeros_like(b_dev), M)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        _, it, res = api.pcg(S, b_dev, xs[args.warmup + k], M)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert it == its, "iteration count changed between solves"
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    loop_its = its - 1
+    value = args.steps * loop_its / elapsed
+    relres = float(res[-1] / np.linalg.norm(b_host))
+
+    # ---------------- roofline of the dominant kernel (S-apply GEMV), HIP events on the library stream
+    _, bytes_dom = S.bytes()
+    e0, e1 = api.Event(ctx), api.Event(ctx)
+    S.apply_dominant(b_dev, reps=20)
+    ctx.synchronize()
+    e0.record()
+    S.apply_dominant(b_dev, reps=args.kernel_reps)
+    e1.record()
+    k_ms = e0.elapsed_ms(e1) / args.kernel_reps
+    achieved = bytes_dom / (k_ms * 1e-3) / 1e9
+    _, bytes_nn = M.bytes()
+    M.apply_dominant(b_dev, reps=20)
+    ctx.synchronize()
+    e0.record()
+    M.apply_dominant(b_dev, reps=args.kernel_reps)
+    e1.record()
+    nn_ms = e0.elapsed_ms(e1) / args.kernel_reps
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/hbm_traffic.py from rocprofv3 --pmc passes
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("k_gemv_batched_S_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_gemv_batched<S-apply>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "bytes_per_launch": int(bytes_dom), "us_per_launch": round(k_ms * 1e3, 3),
+                "nn_apply_GBs": round(bytes_nn / (nn_ms * 1e-3) / 1e9, 1), "nn_us_per_launch": round(nn_ms * 1e3, 3)}
+
+    # ---------------- CPU baseline: the oracle (C restatement) on this box's host cores, rank 0, N=1 only
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        # the box shows every logical CPU of the host but a 1-GPU job owns a 16-core share
+        cores = orc.set_threads(min(len(os.sched_getaffinity(0)), 16))
+        So = orc.apply_local_schurs_operator(P.Sd, P.sub.gather_idx, n_Γ)
+        Mo = orc.neumann_neumann_operator(P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+        xo, ito, reso = orc.pcg(So, b_host, np.zeros(n_Γ), Mo)   # also the parity check of this run
+        assert ito == its, f"GPU it={its} but oracle it={ito}"
+        assert np.allclose(res, reso, rtol=1e-8, atol=1e-12 * reso[0])
+        nsolve, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0:
+            orc.pcg(So, b_host, np.zeros(n_Γ), Mo)
+            nsolve += 1
+        tc = time.perf_counter() - t0
+        cpu = {"value": round(nsolve * (ito - 1) / tc, 2), "unit": "iterations/s", "cores": cores, "kind": "port",
+               "sample": f"{nsolve} full NN-PCG solves of the same 1M-DoF Schur system in {tc:.1f}s "
+                         "(C restatement of cg.jl/EPDD.jl, OpenMP row-parallel GEMV; not Julia)"}
+
+    if rank == 0:
+        out = {
+            "metric": "Schur-PCG iterations/sec (NN-preconditioned, assembled local Schurs), 1M DoF",
+            "value": round(value, 1), "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"configs[2]: N={args.N} structured P1 mesh, {n_free} free DoF, {ndom} subdomains "
+                                   f"({args.px}x{args.py} boxes), lognormal a=exp(g) seed {args.seed}, n_Γ={n_Γ}; "
+                                   "pcg(S, b_schur, 0, ΠSnn), eps=1e-7",
+                       "subdomains_per_gpu": hi - lo, "it": its, "loop_iterations_per_solve": loop_its,
+                       "final_relres": relres, "graph_chunk": args.chunk},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,7 @@ struct SolverState {
   double rTr, rTz;            // current r'r and r'z
   double rTr_prev, rTz_prev;  // values before this iteration's update (for beta = (1/old)*new)
   double d, alpha, beta;      // diagnostics (each workgroup recomputes them from the partials)
-  double tol, bnorm;
+  double tol, bnorm, eps;
   long long it, maxit, res_cap;
   int done;
   int overflow;               // res_norm capacity hit (BoundsError in the reference)
@@ -133,38 +133,72 @@ __global__ __launch_bounds__(NT) void k_spmv_csr(int nblocks, const int *__restr
 }
 
 // ------------------------------------------------------------------ batched dense GEMV with fused gather
-// y_loc[d] = M_d * (D_d R_d x)  [* D_d], for all subdomains d of this rank in one launch.
+// y_d = M_d * (D_d R_d x)  [* D_d], for all subdomains d of this rank in one launch.
 //   S-apply  (SCALE=false): M_d = S_d,  EPDD.jl:775-778  (gather, `Sd[idom]*xd`)
 //   NN-apply (SCALE=true) : M_d = ΠS_d, EPDD.jl:1373-1381 (gather r/cnt, `ΠSd[idom]*rd`, result /cnt)
 // Layout: every M_d is stored row-major with its leading dimension padded to a multiple of 16
 // doubles (128 B), so each row is a contiguous, line-aligned stream. A workgroup owns RPW rows per
-// wave (4*RPW rows); x_d is gathered once per workgroup into LDS (padded with zeros); each lane
-// streams 16 B per row per step (1 KiB per wave-instruction), multiplies against the LDS copy of
-// x_d and the row sum is finished with a wave shuffle tree. The scatter-add over subdomains is a
-// separate deterministic pass (k_assemble) in the reference's idom-ascending order.
+// wave (4*RPW rows) described by ONE 32-byte tile record. The first group of matrix loads is issued
+// before x_d is gathered into LDS (padded with zeros), so the stream is already in flight while
+// the index->x->LDS chain and the barrier complete; after that two groups (2 x 4 x 16 B per lane
+// and row) stay in flight. Each lane multiplies against the LDS copy of x_d and the row sum is
+// finished with a wave shuffle tree.
+// Output: row r of subdomain d goes to out_pos[...] = g*W + j, the j-th contribution slot of Γ node
+// g (slots in ascending subdomain order, W = max multiplicity; unused slots stay 0). The
+// scatter-add over subdomains `Sx[lΓ] += Sdxd[lΓd]` (EPDD.jl:779-781 / 1379-1381) is then a
+// contiguous W-term sum per Γ node, taken by the consumer kernel in the reference's idom order.
+struct GemvTile {
+  long long mat_off;  // element offset of the subdomain block
+  int n, ld;          // n_Γd and padded leading dimension
+  int loc_off, row0;  // offset of the block in the local index space, first row of this tile
+  int pad0, pad1;
+};
 struct DenseMeta {
-  const double *M;           // all blocks of this rank, row-major, padded
-  const long long *mat_off;  // [ndl] element offset of block d
-  const int *n;              // [ndl] n_Γd
-  const int *ld;             // [ndl] padded leading dimension
-  const int *loc_off;        // [ndl] offset of block d in the concatenated local vectors
-  const int *gidx;           // [nloc] Γ index of every local slot
-  const double *cnt;         // [nloc] node_Γ_cnt as double (NN only)
-  const int *tile_dom;       // [ntiles]
-  const int *tile_row0;      // [ntiles]
+  const double *M;        // all blocks of this rank, row-major, padded
+  const GemvTile *tiles;  // [ntiles]
+  const int *gidx;        // [nloc] Γ index of every local row/column
+  const double *cnt;      // [nloc] node_Γ_cnt as double (NN only)
+  const int *out_pos;     // [nloc] slot g*W + j of every local row
 };
 constexpr int GEMV_PANEL = 2048;  // doubles of x_d staged per pass (16 KiB LDS)
 
-template <int RPW, bool SCALE>
+template <int RPW>
+__device__ __forceinline__ void gemv_load_group(double2 (&mv)[RPW][4], const double *const (&rowp)[RPW], int col0,
+                                                int cb, int pw, int lane) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = cb + u * 128 + lane * 2;
+#pragma unroll
+    for (int k = 0; k < RPW; ++k)
+      mv[k][u] = (c < pw) ? *reinterpret_cast<const double2 *>(rowp[k] + col0 + c) : make_double2(0.0, 0.0);
+  }
+}
+
+template <int RPW>
+__device__ __forceinline__ void gemv_fma_group(double (&acc)[RPW], const double2 (&mv)[RPW][4], const double *xs, int cb,
+                                               int pw, int lane) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = cb + u * 128 + lane * 2;
+    const double2 xv = (c < pw) ? *reinterpret_cast<const double2 *>(&xs[c]) : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      acc[k] += mv[k][u].x * xv.x;
+      acc[k] += mv[k][u].y * xv.y;
+    }
+  }
+}
+
+template <int RPW, bool SCALE, int PIPE>  // PIPE 1: two load groups in flight (ping-pong); 0: one
 __global__ __launch_bounds__(NT) void k_gemv_batched(DenseMeta m, const double *__restrict__ x,
-                                                     double *__restrict__ yloc, const int *done) {
+                                                     double *__restrict__ yslots, const int *done) {
   if (done && *done) return;
   __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
-  const int d = m.tile_dom[blockIdx.x];
-  const int n = m.n[d], ld = m.ld[d], off = m.loc_off[d];
+  const GemvTile t = m.tiles[blockIdx.x];
+  const int n = t.n, ld = t.ld, off = t.loc_off;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int row_base = m.tile_row0[blockIdx.x] + w * RPW;
-  const double *Md = m.M + m.mat_off[d];
+  const int row_base = t.row0 + w * RPW;
+  const double *Md = m.M + t.mat_off;
   const double *rowp[RPW];
   double acc[RPW];
 #pragma unroll
@@ -173,9 +207,14 @@ __global__ __launch_bounds__(NT) void k_gemv_batched(DenseMeta m, const double *
     rowp[k] = Md + (long long)r * ld;
     acc[k] = 0.0;
   }
+  double2 bufA[RPW][4], bufB[RPW][4];
+  gemv_load_group<RPW>(bufA, rowp, 0, 0, min(GEMV_PANEL, ld), lane);  // in flight during the gather below
   for (int c0 = 0; c0 < ld; c0 += GEMV_PANEL) {
     const int pw = min(GEMV_PANEL, ld - c0);  // multiple of 16
-    if (c0) __syncthreads();
+    if (c0) {
+      __syncthreads();
+      gemv_load_group<RPW>(bufA, rowp, c0, 0, pw, lane);
+    }
     for (int l = threadIdx.x; l < pw; l += NT) {
       const int j = c0 + l;
       double v = 0.0;
@@ -186,37 +225,32 @@ __global__ __launch_bounds__(NT) void k_gemv_batched(DenseMeta m, const double *
       xs[l] = v;
     }
     __syncthreads();
-    for (int cb = 0; cb < pw; cb += 512) {
-      double2 mv[RPW][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = cb + u * 128 + lane * 2;
-#pragma unroll
-        for (int k = 0; k < RPW; ++k)
-          mv[k][u] = (c < pw) ? *reinterpret_cast<const double2 *>(rowp[k] + c0 + c) : make_double2(0.0, 0.0);
+    if (PIPE) {
+      // ping-pong: two groups of 4 x 16 B per lane and row in flight; loads past pw are predicated off
+      for (int cb = 0; cb < pw; cb += 1024) {
+        gemv_load_group<RPW>(bufB, rowp, c0, cb + 512, pw, lane);
+        gemv_fma_group<RPW>(acc, bufA, xs, cb, pw, lane);
+        gemv_load_group<RPW>(bufA, rowp, c0, cb + 1024, pw, lane);
+        gemv_fma_group<RPW>(acc, bufB, xs, cb + 512, pw, lane);
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = cb + u * 128 + lane * 2;
-        const double2 xv = (c < pw) ? *reinterpret_cast<const double2 *>(&xs[c]) : make_double2(0.0, 0.0);
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-          acc[k] += mv[k][u].x * xv.x;
-          acc[k] += mv[k][u].y * xv.y;
-        }
+    } else {
+      for (int cb = 0; cb < pw; cb += 512) {
+        if (cb) gemv_load_group<RPW>(bufA, rowp, c0, cb, pw, lane);
+        gemv_fma_group<RPW>(acc, bufA, xs, cb, pw, lane);
       }
     }
   }
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
-    const double s = wave_sum(acc[k]);
+    const double sum = wave_sum(acc[k]);
     const int r = row_base + k;
-    if (lane == 0 && r < n) yloc[off + r] = SCALE ? s / m.cnt[off + r] : s;
+    if (lane == 0 && r < n) yslots[m.out_pos[off + r]] = SCALE ? sum / m.cnt[off + r] : sum;
   }
 }
 
 // y[i] = sum of the local contributions to Γ node i, in ascending subdomain order
-// (`Sx[lΓ] += Sdxd[lΓd]` for idom = 1..ndom, EPDD.jl:779-781 / 1379-1381).
+// (`Sx[lΓ] += Sdxd[lΓd]` for idom = 1..ndom, EPDD.jl:779-781 / 1379-1381); indexed form, used by the
+// matrix-free operator whose local results are produced in local order by the SpMV kernel.
 __global__ __launch_bounds__(NT) void k_assemble(int n, const int *__restrict__ aptr, const int *__restrict__ apos,
                                                  const double *__restrict__ yloc, double *__restrict__ y,
                                                  const int *done) {
@@ -224,6 +258,16 @@ __global__ __launch_bounds__(NT) void k_assemble(int n, const int *__restrict__ 
   for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
     double s = 0.0;
     for (int k = aptr[i]; k < aptr[i + 1]; ++k) s += yloc[apos[k]];
+    y[i] = s;
+  }
+}
+// The same sum over the contiguous contribution slots written by k_gemv_batched.
+__global__ __launch_bounds__(NT) void k_assemble_slots(int n, int width, const double *__restrict__ yslots,
+                                                       double *__restrict__ y, const int *done) {
+  if (done && *done) return;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    double s = 0.0;
+    for (int j = 0; j < width; ++j) s += yslots[(long long)i * width + j];
     y[i] = s;
   }
 }
@@ -254,11 +298,13 @@ __global__ __launch_bounds__(NT) void k_residual(int n, const double *__restrict
     if (part_bb) part_bb[blockIdx.x] = sbb;
   }
 }
-// Set-up: it = 1; res_norm[1] = sqrt(r'r); tol = eps*norm2(b) (cg.jl:26-32 / 81-89).
+// Set-up: it = 1; res_norm[1] = sqrt(r'r); tol = eps*norm2(b) (cg.jl:26-32 / 81-89). eps, maxit and
+// res_cap were written into the state block by the host.
 __global__ __launch_bounds__(NT) void k_init_state(SolverState *st, const double *part_rr, const double *part_bb,
-                                                   const double *part_rz, int g, double eps, long long maxit,
-                                                   long long res_cap, double *res_norm) {
+                                                   const double *part_rz, int g, double *res_norm) {
   __shared__ double sm[NT / 64 + 1];
+  const double eps = st->eps;
+  const long long maxit = st->maxit, res_cap = st->res_cap;
   const double rr = sum_partials(part_rr, g, sm);
   const double bb = sum_partials(part_bb, g, sm);
   const double rz = part_rz ? sum_partials(part_rz, g, sm) : rr;
@@ -266,7 +312,7 @@ __global__ __launch_bounds__(NT) void k_init_state(SolverState *st, const double
     st->rTr = rr; st->rTz = rz; st->rTr_prev = rr; st->rTz_prev = rz;
     st->bnorm = sqrt(bb);
     st->tol = eps * st->bnorm;
-    st->it = 1; st->maxit = maxit; st->res_cap = res_cap;
+    st->it = 1;
     st->d = 0.0; st->alpha = 0.0; st->beta = 0.0;
     const double res = sqrt(rr);
     st->overflow = 0;
@@ -337,6 +383,192 @@ __global__ __launch_bounds__(NT) void k_update_p(int n, SolverState *st, const d
     st->done = !((it < st->maxit) && (res > st->tol));
   }
 }
+// ------------------------------------------------------------------ fused single-workgroup kernels (n <= 8192)
+// On the Schur system the Γ-vectors are tiny (n_Γ ≈ 4 k): one 1024-thread workgroup keeps its
+// share of every vector in registers and does Γ-sum + dot + update in one launch, so a PCG
+// iteration is 4 launches (S GEMV, this, NN GEMV, this) instead of 8 latency-bound ones.
+// A vector operand is a "view": width == 0: plain vector src[i]; width == W: the Γ-sum
+// y[i] = Σ_{j<W} src[i*W + j] over the contribution slots of k_gemv_batched (deferred scatter-add).
+// All loads of a kernel are issued up front (one memory round trip), scalars included.
+constexpr int NTF = 1024;
+constexpr int FUSED_MAX_N = NTF * 8;
+
+struct AsmView {
+  const double *src;
+  int width;
+};
+__device__ __forceinline__ double view_load(const AsmView &v, int e) {
+  if (v.width == 0) return v.src[e];
+  double s = 0.0;
+  if (v.width == 4) {
+    const double4 q = *reinterpret_cast<const double4 *>(v.src + 4ll * e);
+    s += q.x; s += q.y; s += q.z; s += q.w;
+  } else if (v.width == 2) {
+    const double2 q = *reinterpret_cast<const double2 *>(v.src + 2ll * e);
+    s += q.x; s += q.y;
+  } else {
+    for (int j = 0; j < v.width; ++j) s += v.src[(long long)e * v.width + j];
+  }
+  return s;
+}
+// Deterministic sum over the 1024-thread workgroup, broadcast. `sm` has NTF/64 + 1 doubles.
+__device__ __forceinline__ double block_sum_f(double v, double *sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < NTF / 64; ++i) t += sm[i];
+    sm[NTF / 64] = t;
+  }
+  __syncthreads();
+  const double t = sm[NTF / 64];
+  __syncthreads();
+  return t;
+}
+// Ap = view; d = p'Ap; alpha = num/d; x += alpha p; r -= alpha Ap; r'r   (cg.jl:36-43 / 93-99)
+template <int EPT>
+__global__ __launch_bounds__(NTF) void k_fused_xr(int n, SolverState *st, AsmView vAp, const double *__restrict__ p,
+                                                  double *__restrict__ x, double *__restrict__ r, int precond) {
+  if (st->done) return;
+  __shared__ double sm[NTF / 64 + 1];
+  const double rTr0 = st->rTr, rTz0 = st->rTz;
+  double pe[EPT], ae[EPT], xe[EPT], re[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = k * NTF + threadIdx.x;
+    pe[k] = ae[k] = xe[k] = re[k] = 0.0;
+    if (e < n) { ae[k] = view_load(vAp, e); pe[k] = p[e]; xe[k] = x[e]; re[k] = r[e]; }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) s += pe[k] * ae[k];
+  const double d = block_sum_f(s, sm);
+  const double alpha = (precond ? rTz0 : rTr0) / d;
+  double srr = 0.0;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = k * NTF + threadIdx.x;
+    if (e < n) {
+      x[e] = xe[k] + alpha * pe[k];
+      const double ri = re[k] + (-alpha) * ae[k];
+      r[e] = ri;
+      srr += ri * ri;
+    }
+  }
+  srr = block_sum_f(srr, sm);
+  if (threadIdx.x == 0) {
+    st->d = d; st->alpha = alpha;
+    st->rTr_prev = rTr0; st->rTz_prev = rTz0;
+    st->rTr = srr;
+  }
+}
+// z = view; r'z; beta = (1/old)*new; p = beta p + z [- W mu]; it += 1; res_norm[it]; stop rule
+// (cg.jl:44-47 / 100-106; defcg.jl:76-80 / 299-305). r'r was stored by k_fused_xr.
+template <int EPT>
+__global__ __launch_bounds__(NTF) void k_fused_p(int n, SolverState *st, AsmView vz, const double *__restrict__ r,
+                                                 double *__restrict__ p, const double *__restrict__ W,
+                                                 const double *__restrict__ mu, int nvec, double *res_norm,
+                                                 int precond) {
+  if (st->done) return;  // written only by thread 0 at the very end, behind the barriers below
+  __shared__ double sm[NTF / 64 + 1];
+  const double rr = st->rTr;
+  const double old = precond ? st->rTz_prev : st->rTr_prev;
+  const double tol = st->tol;
+  const long long it0 = st->it, maxit = st->maxit, cap = st->res_cap;
+  double ze[EPT], pe[EPT];
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = k * NTF + threadIdx.x;
+    ze[k] = pe[k] = 0.0;
+    if (e < n) {
+      ze[k] = view_load(vz, e);
+      pe[k] = p[e];
+      if (precond) s += r[e] * ze[k];
+    }
+  }
+  const double rz = precond ? block_sum_f(s, sm) : rr;
+  double beta = 1. / old;
+  beta *= rz;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = k * NTF + threadIdx.x;
+    if (e < n) {
+      double v = beta * pe[k] + ze[k];
+      if (nvec > 0) {
+        double wm = 0.0;
+        for (int q = 0; q < nvec; ++q) wm += W[(long long)q * n + e] * mu[q];
+        v = v - wm;
+      }
+      p[e] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st->rTz = rz; st->beta = beta;
+    const long long it = it0 + 1;
+    st->it = it;
+    const double res = sqrt(rr);
+    if (it <= cap) res_norm[it - 1] = res; else st->overflow = 1;
+    st->done = !((it < maxit) && (res > tol));
+  }
+}
+// Set-up, first half: r = b - A*x (Ap as a view); r'r and b'b   (cg.jl:28-29,32 / 83-84,88)
+template <int EPT>
+__global__ __launch_bounds__(NTF) void k_fused_residual(int n, SolverState *st, AsmView vAp,
+                                                        const double *__restrict__ b, double *__restrict__ r) {
+  __shared__ double sm[NTF / 64 + 1];
+  double srr = 0.0, sbb = 0.0;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = k * NTF + threadIdx.x;
+    if (e < n) {
+      const double bi = b[e];
+      const double ri = bi - view_load(vAp, e);
+      r[e] = ri;
+      srr += ri * ri;
+      sbb += bi * bi;
+    }
+  }
+  srr = block_sum_f(srr, sm);
+  sbb = block_sum_f(sbb, sm);
+  if (threadIdx.x == 0) { st->rTr = srr; st->bnorm = sqrt(sbb); }
+}
+// Set-up, second half: z = view; r'z; p = z; it = 1; res_norm[1]; tol; stop rule (cg.jl:26-33 / 81-89).
+// eps, maxit, res_cap arrive through st->tol / st->maxit / st->res_cap (written by the host before the
+// launch), so that the launch can live in a replayable graph.
+template <int EPT>
+__global__ __launch_bounds__(NTF) void k_fused_start(int n, SolverState *st, AsmView vz, const double *__restrict__ r,
+                                                     double *__restrict__ p, double *res_norm, int precond) {
+  __shared__ double sm[NTF / 64 + 1];
+  const double rr = st->rTr, bnorm = st->bnorm, eps = st->eps;
+  const long long maxit = st->maxit, cap = st->res_cap;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = k * NTF + threadIdx.x;
+    if (e < n) {
+      const double ze = view_load(vz, e);
+      p[e] = ze;
+      if (precond) s += r[e] * ze;
+    }
+  }
+  const double rz = precond ? block_sum_f(s, sm) : rr;
+  if (threadIdx.x == 0) {
+    st->rTz = rz; st->rTr_prev = rr; st->rTz_prev = rz;
+    const double tol = eps * bnorm;
+    st->tol = tol;
+    st->it = 1;
+    st->d = 0.0; st->alpha = 0.0; st->beta = 0.0;
+    const double res = sqrt(rr);
+    st->overflow = 0;
+    if (cap >= 1) res_norm[0] = res; else st->overflow = 1;
+    st->done = !((1 < maxit) && (res > tol));
+  }
+}
+
 // Set-up of the deflated solvers: p = z - W mu (defcg.jl:61 / 285); plain copy when nvec == 0.
 __global__ __launch_bounds__(NT) void k_init_p(int n, const double *__restrict__ z, double *__restrict__ p,
                                                const double *__restrict__ W, const double *__restrict__ mu, int nvec) {

@@ -31,6 +31,12 @@ struct Operator {
   virtual ~Operator() = default;
   // Enqueue y = Op(x) on ctx->stream; x, y are device pointers, x != y.
   virtual void apply(const double *x, double *y, const int *done) = 0;
+  // Same, but the result may be returned as a deferred "assembled view" (kernels.hpp AsmView) that the
+  // consumer kernel sums on the fly; the default materialises y and returns a plain view of it.
+  virtual AsmView apply_view(const double *x, double *y, const int *done) {
+    apply(x, y, done);
+    return AsmView{y, 0};
+  }
   virtual bool graph_safe() const { return true; }  // false: apply synchronises with the host
   virtual void bytes(int64_t *apply_b, int64_t *dominant_b) const = 0;
   virtual void apply_dominant(const double *x) = 0;
@@ -161,7 +167,8 @@ struct LocalMaps {
   int ndl = 0;   // local subdomains on this rank
   int nloc = 0;  // Σ n_Γd over local subdomains
   std::vector<int> nd, loc_off, gidx_h;
-  DevBuf<int> gidx, aptr, apos;
+  DevBuf<int> gidx, aptr, apos, out_pos;
+  int slot_width = 1;  // W: contribution slots per Γ node (max multiplicity over this rank's subdomains)
   void build(mi_ctx_s *c, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d, const int64_t *const *gather_idx,
              int base, int64_t d0, int64_t d1) {
     if (ndom <= 0 || n_gamma < 0 || n_gamma >= INT32_MAX || !n_gamma_d || !gather_idx || d0 < 0 || d1 > ndom || d0 > d1)
@@ -196,6 +203,14 @@ struct LocalMaps {
     for (int dl = 0; dl < ndl; ++dl)
       for (int l = 0; l < nd[dl]; ++l) pos[next[gidx_h[loc_off[dl] + l]]++] = loc_off[dl] + l;
     gidx.upload(gidx_h, c->stream); aptr.upload(cntv, c->stream); apos.upload(pos, c->stream);
+    // slot form of the same index for the dense operators: local row -> g*W + j, j = rank of the
+    // subdomain among the contributors of Γ node g
+    for (int64_t i = 0; i < n_gamma; ++i) slot_width = std::max(slot_width, cntv[i + 1] - cntv[i]);
+    if (slot_width == 3) slot_width = 4;  // 32-byte aligned slot rows -> one double4 load
+    std::vector<int> op(nloc);
+    for (int64_t i = 0; i < n_gamma; ++i)
+      for (int k = cntv[i]; k < cntv[i + 1]; ++k) op[pos[k]] = (int)(i * slot_width + (k - cntv[i]));
+    out_pos.upload(op, c->stream);
   }
   void assemble(mi_ctx_s *c, int64_t n_gamma, const double *yloc, double *y, const int *done) const {
     hipLaunchKernelGGL(k_assemble, dim3(vec_grid(n_gamma)), dim3(NT), 0, c->stream, (int)n_gamma, aptr.p, apos.p, yloc,
@@ -209,10 +224,9 @@ struct LocalMaps {
 struct DenseBlockOp : Operator {
   LocalMaps maps;
   bool scale;  // true: Neumann-Neumann (gather r/cnt, result /cnt)
-  int rpw, ntiles = 0;
-  DevBuf<double> M, cnt, yloc;
-  DevBuf<long long> mat_off;
-  DevBuf<int> nd, ld, loc_off, tile_dom, tile_row0;
+  int rpw, pipe, ntiles = 0;
+  DevBuf<double> M, cnt, yslots;
+  DevBuf<GemvTile> tiles;
   int64_t alg_bytes = 0;
   DenseMeta meta{};
 
@@ -223,18 +237,20 @@ struct DenseBlockOp : Operator {
     maps.build(c, ndom, n_gamma, n_gamma_d, gather_idx, base, d0, d1);
     rpw = env_int("MI355_GEMV_RPW", 2);
     if (rpw != 1 && rpw != 2 && rpw != 4) rpw = 2;
+    pipe = env_int("MI355_GEMV_PIPE", 0) ? 1 : 0;
     std::vector<long long> moff;
-    std::vector<int> ldv, tdom, trow;
+    std::vector<int> ldv;
+    std::vector<GemvTile> tv;
     long long tot = 0;
     for (int dl = 0; dl < maps.ndl; ++dl) {
       const int n_d = maps.nd[dl], l = (n_d + 15) / 16 * 16;
       if (n_d && !blocks[d0 + dl]) raise(MI_ERR_BAD_ARG, "dense block %d is NULL", dl);
       moff.push_back(tot); ldv.push_back(l);
+      for (int r = 0; r < n_d; r += 4 * rpw) tv.push_back(GemvTile{tot, n_d, l, maps.loc_off[dl], r, 0, 0});
       tot += (long long)n_d * l;
-      for (int r = 0; r < n_d; r += 4 * rpw) { tdom.push_back(dl); trow.push_back(r); }
       alg_bytes += 8ll * n_d * n_d + 16ll * n_d + 4ll * n_d;
     }
-    ntiles = (int)tdom.size();
+    ntiles = (int)tv.size();
     M.alloc((size_t)tot);
     // column-major (Julia) -> padded row-major, one block at a time
     for (int dl = 0; dl < maps.ndl; ++dl) {
@@ -255,24 +271,33 @@ struct DenseBlockOp : Operator {
       }
       cnt.upload(cv, c->stream);
     }
-    mat_off.upload(moff, c->stream); nd.upload(maps.nd, c->stream); ld.upload(ldv, c->stream);
-    loc_off.upload(maps.loc_off, c->stream); tile_dom.upload(tdom, c->stream); tile_row0.upload(trow, c->stream);
-    yloc.alloc((size_t)maps.nloc + 1);
-    yloc.zero(c->stream);
+    tiles.upload(tv, c->stream);
+    yslots.alloc((size_t)n_gamma * maps.slot_width + 4);
+    yslots.zero(c->stream);  // unused slots stay 0 for the lifetime of the operator
     MI_HIP(hipStreamSynchronize(c->stream));
-    meta = DenseMeta{M.p, mat_off.p, nd.p, ld.p, loc_off.p, maps.gidx.p, scale ? cnt.p : nullptr, tile_dom.p, tile_row0.p};
+    meta = DenseMeta{M.p, tiles.p, maps.gidx.p, scale ? cnt.p : nullptr, maps.out_pos.p};
   }
   void gemv(const double *x, const int *done) {
     if (!ntiles) return;
-#define MI_GEMV(R, S) hipLaunchKernelGGL((k_gemv_batched<R, S>), dim3(ntiles), dim3(NT), 0, ctx->stream, meta, x, yloc.p, done)
-    if (scale) { if (rpw == 1) MI_GEMV(1, true); else if (rpw == 2) MI_GEMV(2, true); else MI_GEMV(4, true); }
-    else       { if (rpw == 1) MI_GEMV(1, false); else if (rpw == 2) MI_GEMV(2, false); else MI_GEMV(4, false); }
+#define MI_GEMV(R, S, P) hipLaunchKernelGGL((k_gemv_batched<R, S, P>), dim3(ntiles), dim3(NT), 0, ctx->stream, meta, x, yslots.p, done)
+#define MI_GEMV_S(R, P) do { if (scale) MI_GEMV(R, true, P); else MI_GEMV(R, false, P); } while (0)
+    if (pipe) { if (rpw == 1) MI_GEMV_S(1, 1); else if (rpw == 2) MI_GEMV_S(2, 1); else MI_GEMV_S(4, 1); }
+    else      { if (rpw == 1) MI_GEMV_S(1, 0); else if (rpw == 2) MI_GEMV_S(2, 0); else MI_GEMV_S(4, 0); }
+#undef MI_GEMV_S
 #undef MI_GEMV
     MI_HIP(hipGetLastError());
   }
   void apply(const double *x, double *y, const int *done) override {
     gemv(x, done);
-    maps.assemble(ctx, n, yloc.p, y, done);
+    hipLaunchKernelGGL(k_assemble_slots, dim3(vec_grid(n)), dim3(NT), 0, ctx->stream, (int)n, maps.slot_width,
+                       yslots.p, y, done);
+    MI_HIP(hipGetLastError());
+    ctx->allreduce(y, (size_t)n);
+  }
+  AsmView apply_view(const double *x, double *y, const int *done) override {
+    if (ctx->comm) return Operator::apply_view(x, y, done);  // the Γ-sum must be materialised for the all-reduce
+    gemv(x, done);
+    return AsmView{yslots.p, maps.slot_width};
   }
   void bytes(int64_t *a, int64_t *d) const override { *a = alg_bytes + 8 * n; *d = alg_bytes; }
   void apply_dominant(const double *x) override { gemv(x, nullptr); }

@@ -2,12 +2,18 @@
 //
 // One iteration is a fixed sequence of kernel launches whose scalars (alpha, beta, r'r, r'z, it,
 // the stop flag) live in HBM (`SolverState`), so the host never reads a scalar inside the loop.
-// `chunk` iterations are captured once into a hipGraph and replayed; after every replay the host
-// looks at the stop flag of the PREVIOUS replay (one replay of run-ahead). Launches that follow the
-// iteration at which the stop rule fired return immediately (`done`), so the iterates, `it` and
-// `res_norm` are exactly those of the reference's `while (it < maxit) && (res_norm[it] > tol)`.
+// Iterations are captured into hipGraphs and replayed; launches that follow the iteration at which
+// the stop rule fired return immediately (`done`), so the iterates, `it` and `res_norm` are exactly
+// those of the reference's `while (it < maxit) && (res_norm[it] > tol)` whatever the replay sizes.
+//
+// Replay policy: the first replay holds the set-up (r = b - A x, z = M \ r, p = z, it = 1) plus as
+// many iterations as the previous solve with the same (A, M) needed, so a repeated or similar solve
+// (Example07's realization loop) is ONE graph launch and ONE host wait; result copies are enqueued
+// speculatively behind it. If the stop flag is not up, `chunk`-sized replays follow, the host
+// looking at the flag of the PREVIOUS replay (one replay of run-ahead).
 #pragma once
 #include <cmath>
+#include <cstddef>
 #include <tuple>
 
 #include "operators.hpp"
@@ -19,10 +25,16 @@ struct PinnedFlags {
   int done;
   int overflow;
 };
+struct PinnedParams {
+  double eps;
+  long long maxit, res_cap;
+};
+
+constexpr int64_t RES_STAGE = 8192;
 
 struct GraphKey {
   const Operator *A, *M;
-  int nvec, chunk;
+  int nvec, chunk;  // chunk > 0: that many iterations; chunk < 0: set-up + (-chunk) iterations
   bool operator<(const GraphKey &o) const {
     return std::tie(A, M, nvec, chunk) < std::tie(o.A, o.M, o.nvec, o.chunk);
   }
@@ -30,29 +42,47 @@ struct GraphKey {
 
 struct SolverWorkspace {
   int64_t n = 0;
-  int g = 1;  // workgroups of the vector kernels = number of partials per dot
-  DevBuf<double> r, z, p, Ap, x, b;
-  DevBuf<double> part_pAp, part_rr, part_rz, part_bb, res_norm;
-  DevBuf<SolverState> st;
+  int g = 1;  // workgroups of the multi-workgroup vector kernels = number of partials per dot
+  // One slab for the state, the partials and the six work vectors: the latency-bound loop kernels
+  // then touch a handful of pages instead of one per allocation.
+  DevBuf<char> slab;
+  SolverState *st = nullptr;
+  double *part_pAp = nullptr, *part_rr = nullptr, *part_rz = nullptr, *part_bb = nullptr;
+  double *r = nullptr, *z = nullptr, *p = nullptr, *Ap = nullptr, *x = nullptr, *b = nullptr;
+  DevBuf<double> res_norm;
   // deflation
   DevBuf<double> W, AW, LU, mu, part_mu, gram;
   DevBuf<int> piv;
   int nvec_cap = 0;
-  PinnedFlags *flags = nullptr;  // 2 slots, pinned
+  PinnedFlags *flags = nullptr;    // 2 slots, pinned
+  PinnedParams *params = nullptr;  // pinned source of eps / maxit / res_cap
+  double *res_stage = nullptr;     // pinned landing zone for short residual histories
   hipEvent_t ev[2] = {nullptr, nullptr};
   std::map<GraphKey, hipGraphExec_t> graphs;
+  std::map<GraphKey, int> predicted;  // loop iterations the last solve with this (A, M, nvec) took
 
   explicit SolverWorkspace(int64_t n_) : n(n_), g(vec_grid(n_)) {
-    const size_t m = (size_t)n + 2;
-    r.alloc(m); z.alloc(m); p.alloc(m); Ap.alloc(m); x.alloc(m); b.alloc(m);
-    part_pAp.alloc(MAX_PARTS); part_rr.alloc(MAX_PARTS); part_rz.alloc(MAX_PARTS); part_bb.alloc(MAX_PARTS);
-    st.alloc(1);
+    auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t vec = pad(sizeof(double) * ((size_t)n + 2)), part = pad(sizeof(double) * MAX_PARTS);
+    const size_t total = pad(sizeof(SolverState)) + 4 * part + 6 * vec;
+    slab.alloc(total);
+    MI_HIP(hipMemset(slab.p, 0, total));
+    char *q = slab.p;
+    st = (SolverState *)q; q += pad(sizeof(SolverState));
+    part_pAp = (double *)q; q += part; part_rr = (double *)q; q += part;
+    part_rz = (double *)q; q += part; part_bb = (double *)q; q += part;
+    r = (double *)q; q += vec; z = (double *)q; q += vec; p = (double *)q; q += vec;
+    Ap = (double *)q; q += vec; x = (double *)q; q += vec; b = (double *)q; q += vec;
     MI_HIP(hipHostMalloc((void **)&flags, 2 * sizeof(PinnedFlags)));
+    MI_HIP(hipHostMalloc((void **)&params, sizeof(PinnedParams)));
+    MI_HIP(hipHostMalloc((void **)&res_stage, RES_STAGE * sizeof(double)));
     for (auto &e : ev) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   ~SolverWorkspace() {
     drop_graphs();
     if (flags) (void)hipHostFree(flags);
+    if (params) (void)hipHostFree(params);
+    if (res_stage) (void)hipHostFree(res_stage);
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
   }
   void drop_graphs() {
@@ -62,6 +92,9 @@ struct SolverWorkspace {
   void drop_graphs_of(const Operator *op) {
     for (auto it = graphs.begin(); it != graphs.end();)
       if (it->first.A == op || it->first.M == op) { (void)hipGraphExecDestroy(it->second); it = graphs.erase(it); }
+      else ++it;
+    for (auto it = predicted.begin(); it != predicted.end();)
+      if (it->first.A == op || it->first.M == op) it = predicted.erase(it);
       else ++it;
   }
   void ensure_deflation(int nvec) {
@@ -111,11 +144,13 @@ struct Krylov {
   int nvec;
   int n, g;
   hipStream_t s;
+  bool fused;  // single-workgroup loop kernels (small Γ systems)
 
   Krylov(mi_ctx_s *c, Operator *A_, Operator *M_, int nvec_)
-      : ctx(c), A(A_), M(M_), ws(workspace(c, A_->n)), nvec(nvec_), n((int)A_->n), g(ws.g), s(c->stream) {}
+      : ctx(c), A(A_), M(M_), ws(workspace(c, A_->n)), nvec(nvec_), n((int)A_->n), g(ws.g), s(c->stream),
+        fused(A_->n <= FUSED_MAX_N && !env_int("MI355_NO_FUSED", 0)) {}
 
-  const int *done() const { return &ws.st.p->done; }
+  const int *done() const { return &ws.st->done; }
 
   void dot_partial(const double *x, const double *y, double *part, const int *dn) {
     hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(NT), 0, s, n, x, y, part, dn);
@@ -129,27 +164,86 @@ struct Krylov {
     MI_HIP(hipGetLastError());
   }
 
+#define MI_EPT_DISPATCH(CALL)            \
+  do {                                   \
+    if (n <= NTF) { CALL(1); }           \
+    else if (n <= 2 * NTF) { CALL(2); }  \
+    else if (n <= 4 * NTF) { CALL(4); }  \
+    else { CALL(8); }                    \
+  } while (0)
+
   // One loop iteration (cg.jl:35-47 / 92-106; defcg.jl:68-80 / 291-305), enqueued on the stream.
   void iteration() {
     const int *dn = done();
     const int pre = M != nullptr;
-    A->apply(ws.p.p, ws.Ap.p, dn);                                   // mul!(Ap, A, p)
-    dot_partial(ws.p.p, ws.Ap.p, ws.part_pAp.p, dn);                 // d = dot(p, Ap)
-    hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(NT), 0, s, n, ws.st.p, ws.part_pAp.p, g, ws.p.p, ws.Ap.p, ws.x.p,
-                       ws.r.p, ws.part_rr.p, pre);                   // alpha; x += alpha p; r -= alpha Ap; r'r
-    const double *zz = ws.r.p;
-    if (pre) {
-      M->apply(ws.r.p, ws.z.p, dn);                                  // z .= M \ r
-      dot_partial(ws.r.p, ws.z.p, ws.part_rz.p, dn);                 // rTz = dot(r, z)
-      zz = ws.z.p;
+    const double *Wp = nvec > 0 ? ws.W.p : nullptr, *mup = nvec > 0 ? ws.mu.p : nullptr;
+    if (fused) {
+      // small Γ systems: 4 launches per iteration (GEMV, fused, GEMV, fused)
+      const AsmView vAp = A->apply_view(ws.p, ws.Ap, dn);             // mul!(Ap, A, p), Γ-sum deferred
+#define MI_CALL(E) hipLaunchKernelGGL((k_fused_xr<E>), dim3(1), dim3(NTF), 0, s, n, ws.st, vAp, ws.p, ws.x, ws.r, pre)
+      MI_EPT_DISPATCH(MI_CALL);                                       // alpha; x += alpha p; r -= alpha Ap; r'r
+#undef MI_CALL
+      AsmView vz{ws.r, 0};
+      if (pre) {
+        if (nvec > 0) { M->apply(ws.r, ws.z, dn); vz = AsmView{ws.z, 0}; }  // WtA*z needs z itself
+        else vz = M->apply_view(ws.r, ws.z, dn);                     // z .= M \ r, Γ-sum deferred
+      }
+      if (nvec > 0) project(ws.AW.p, vz.src, dn);                     // mu .= WtAW \ (WtA * z)
+#define MI_CALL(E) hipLaunchKernelGGL((k_fused_p<E>), dim3(1), dim3(NTF), 0, s, n, ws.st, vz, ws.r, ws.p, Wp, mup, nvec, ws.res_norm.p, pre)
+      MI_EPT_DISPATCH(MI_CALL);                                       // beta; p; it += 1; res_norm[it]; stop rule
+#undef MI_CALL
+      MI_HIP(hipGetLastError());
+      return;
     }
-    if (nvec > 0) project(ws.AW.p, zz, dn);                          // mu .= WtAW \ (WtA * z)
-    hipLaunchKernelGGL(k_update_p, dim3(g), dim3(NT), 0, s, n, ws.st.p, ws.part_rr.p, ws.part_rz.p, g, zz, ws.p.p,
-                       nvec > 0 ? ws.W.p : (const double *)nullptr, nvec > 0 ? ws.mu.p : (const double *)nullptr, nvec,
-                       ws.res_norm.p, pre);                          // beta; p; it += 1; res_norm[it]; stop rule
+    A->apply(ws.p, ws.Ap, dn);                                        // mul!(Ap, A, p)
+    dot_partial(ws.p, ws.Ap, ws.part_pAp, dn);                        // d = dot(p, Ap)
+    hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(NT), 0, s, n, ws.st, ws.part_pAp, g, ws.p, ws.Ap, ws.x, ws.r,
+                       ws.part_rr, pre);                              // alpha; x += alpha p; r -= alpha Ap; r'r
+    const double *zz = ws.r;
+    if (pre) {
+      M->apply(ws.r, ws.z, dn);                                       // z .= M \ r
+      dot_partial(ws.r, ws.z, ws.part_rz, dn);                        // rTz = dot(r, z)
+      zz = ws.z;
+    }
+    if (nvec > 0) project(ws.AW.p, zz, dn);                           // mu .= WtAW \ (WtA * z)
+    hipLaunchKernelGGL(k_update_p, dim3(g), dim3(NT), 0, s, n, ws.st, ws.part_rr, ws.part_rz, g, zz, ws.p, Wp, mup, nvec,
+                       ws.res_norm.p, pre);                           // beta; p; it += 1; res_norm[it]; stop rule
     MI_HIP(hipGetLastError());
   }
 
+  // r = b - A x; z = M \ r; p = z [- W mu]; it = 1; res_norm[1]; tol (cg.jl:26-33 / 81-89; defcg.jl:56-66 / 277-288).
+  // eps / maxit / res_cap are read from the state block (uploaded by solve()), so this is graph-replayable.
+  void setup_tail() {
+    const int pre = M != nullptr;
+    if (fused && nvec == 0) {
+      const AsmView vAp = A->apply_view(ws.x, ws.Ap, nullptr);
+#define MI_CALL(E) hipLaunchKernelGGL((k_fused_residual<E>), dim3(1), dim3(NTF), 0, s, n, ws.st, vAp, ws.b, ws.r)
+      MI_EPT_DISPATCH(MI_CALL);
+#undef MI_CALL
+      const AsmView vz = pre ? M->apply_view(ws.r, ws.z, nullptr) : AsmView{ws.r, 0};
+#define MI_CALL(E) hipLaunchKernelGGL((k_fused_start<E>), dim3(1), dim3(NTF), 0, s, n, ws.st, vz, ws.r, ws.p, ws.res_norm.p, pre)
+      MI_EPT_DISPATCH(MI_CALL);
+#undef MI_CALL
+      MI_HIP(hipGetLastError());
+      return;
+    }
+    A->apply(ws.x, ws.Ap, nullptr);
+    hipLaunchKernelGGL(k_residual, dim3(g), dim3(NT), 0, s, n, ws.b, ws.Ap, ws.r, ws.part_rr, ws.part_bb);
+    const double *zz = ws.r;
+    if (pre) {
+      M->apply(ws.r, ws.z, nullptr);
+      dot_partial(ws.r, ws.z, ws.part_rz, nullptr);
+      zz = ws.z;
+    }
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(NT), 0, s, ws.st, ws.part_rr, ws.part_bb,
+                       pre ? ws.part_rz : (const double *)nullptr, g, ws.res_norm.p);
+    if (nvec > 0) project(ws.AW.p, zz, nullptr);
+    hipLaunchKernelGGL(k_init_p, dim3(g), dim3(NT), 0, s, n, zz, ws.p, nvec > 0 ? ws.W.p : (const double *)nullptr,
+                       nvec > 0 ? ws.mu.p : (const double *)nullptr, nvec);
+    MI_HIP(hipGetLastError());
+  }
+
+  // chunk > 0: `chunk` iterations; chunk < 0: set-up tail + (-chunk) iterations.
   hipGraphExec_t graph(int chunk) {
     GraphKey key{A, M, nvec, chunk};
     auto it = ws.graphs.find(key);
@@ -157,7 +251,8 @@ struct Krylov {
     hipGraph_t gr = nullptr;
     MI_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     try {
-      for (int k = 0; k < chunk; ++k) iteration();
+      if (chunk < 0) setup_tail();
+      for (int k = 0; k < std::abs(chunk); ++k) iteration();
     } catch (...) {
       (void)hipStreamEndCapture(s, &gr);
       if (gr) (void)hipGraphDestroy(gr);
@@ -173,9 +268,8 @@ struct Krylov {
   }
 
   void fetch_flags(int slot) {
-    // it/done/overflow are contiguous at the end of SolverState
-    MI_HIP(hipMemcpyAsync(&ws.flags[slot].it, &ws.st.p->it, sizeof(long long), hipMemcpyDeviceToHost, s));
-    MI_HIP(hipMemcpyAsync(&ws.flags[slot].done, &ws.st.p->done, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipMemcpyAsync(&ws.flags[slot].it, &ws.st->it, sizeof(long long), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipMemcpyAsync(&ws.flags[slot].done, &ws.st->done, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     MI_HIP(hipEventRecord(ws.ev[slot], s));
   }
 
@@ -185,12 +279,14 @@ struct Krylov {
     if (eps <= 0.0) eps = 1e-7;           // RecyclingKrylovSolvers.jl:21
     if (maxit == 0) maxit = n;            // cg.jl:25
     const int64_t cap_dev = std::min<int64_t>(maxit, (int64_t)n) + 1;  // reference: res_norm has n entries
-    ws.res_norm.ensure((size_t)cap_dev);
+    if ((size_t)cap_dev > ws.res_norm.n) { ws.drop_graphs(); ws.res_norm.alloc((size_t)cap_dev); }
     if (nvec > 0) ws.ensure_deflation(nvec);
     const size_t vb = sizeof(double) * (size_t)n;
-    MI_HIP(hipMemcpyAsync(ws.b.p, b_in, vb, hipMemcpyDeviceToDevice, s));
-    MI_HIP(hipMemcpyAsync(ws.x.p, x_io, vb, hipMemcpyDeviceToDevice, s));
-    const int pre = M != nullptr;
+    MI_HIP(hipMemcpyAsync(ws.b, b_in, vb, hipMemcpyDeviceToDevice, s));
+    MI_HIP(hipMemcpyAsync(ws.x, x_io, vb, hipMemcpyDeviceToDevice, s));
+    *ws.params = PinnedParams{eps, (long long)maxit, (long long)cap_dev};
+    MI_HIP(hipMemcpyAsync(&ws.st->eps, &ws.params->eps, sizeof(double), hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(&ws.st->maxit, &ws.params->maxit, 2 * sizeof(long long), hipMemcpyHostToDevice, s));
 
     if (nvec > 0) {
       // defcg.jl:40-54 / 260-275
@@ -207,66 +303,69 @@ struct Krylov {
       ws.LU.upload(lu.data(), lu.size(), s);
       ws.piv.upload(piv.data(), piv.size(), s);
       MI_HIP(hipStreamSynchronize(s));
-      A->apply(ws.x.p, ws.Ap.p, nullptr);                                    // r .= b .- A*x
-      hipLaunchKernelGGL(k_residual, dim3(g), dim3(NT), 0, s, n, ws.b.p, ws.Ap.p, ws.r.p, ws.part_rr.p, ws.part_bb.p);
-      project(ws.W.p, ws.r.p, nullptr);                                      // mu = WtAW \ (W'r)
-      hipLaunchKernelGGL(k_add_Wmu, dim3(g), dim3(NT), 0, s, n, ws.x.p, ws.W.p, ws.mu.p, nvec);  // x .+= W*mu
+      A->apply(ws.x, ws.Ap, nullptr);                                        // r .= b .- A*x
+      hipLaunchKernelGGL(k_residual, dim3(g), dim3(NT), 0, s, n, ws.b, ws.Ap, ws.r, ws.part_rr, ws.part_bb);
+      project(ws.W.p, ws.r, nullptr);                                        // mu = WtAW \ (W'r)
+      hipLaunchKernelGGL(k_add_Wmu, dim3(g), dim3(NT), 0, s, n, ws.x, ws.W.p, ws.mu.p, nvec);  // x .+= W*mu
       MI_HIP(hipGetLastError());
     }
-    // cg.jl:27-32 / 82-89; defcg.jl:58-66 / 279-288
-    A->apply(ws.x.p, ws.Ap.p, nullptr);
-    hipLaunchKernelGGL(k_residual, dim3(g), dim3(NT), 0, s, n, ws.b.p, ws.Ap.p, ws.r.p, ws.part_rr.p, ws.part_bb.p);
-    const double *zz = ws.r.p;
-    if (pre) {
-      M->apply(ws.r.p, ws.z.p, nullptr);
-      dot_partial(ws.r.p, ws.z.p, ws.part_rz.p, nullptr);
-      zz = ws.z.p;
-    }
-    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(NT), 0, s, ws.st.p, ws.part_rr.p, ws.part_bb.p,
-                       pre ? ws.part_rz.p : (const double *)nullptr, g, eps, (long long)maxit, (long long)cap_dev,
-                       ws.res_norm.p);
-    if (nvec > 0) project(ws.AW.p, zz, nullptr);
-    hipLaunchKernelGGL(k_init_p, dim3(g), dim3(NT), 0, s, n, zz, ws.p.p, nvec > 0 ? ws.W.p : (const double *)nullptr,
-                       nvec > 0 ? ws.mu.p : (const double *)nullptr, nvec);
-    MI_HIP(hipGetLastError());
 
-    // ---- the loop
+    // ---- set-up tail + loop
     const bool use_graph = ctx->chunk > 0 && A->graph_safe() && (!M || M->graph_safe());
-    const int64_t max_launch = use_graph ? (maxit + ctx->chunk - 1) / ctx->chunk + 2 : maxit + 2;
+    const int64_t ncap = std::min<int64_t>(res_cap, cap_dev);
+    const bool spec_res = res_host && ncap > 0 && ncap <= RES_STAGE;
+    auto enqueue_results = [&](int slot) {
+      fetch_flags(slot);
+      MI_HIP(hipMemcpyAsync(x_io, ws.x, vb, hipMemcpyDeviceToDevice, s));
+      if (spec_res) MI_HIP(hipMemcpyAsync(ws.res_stage, ws.res_norm.p, sizeof(double) * ncap, hipMemcpyDeviceToHost, s));
+    };
     if (use_graph) {
-      hipGraphExec_t ex = graph(ctx->chunk);
-      int slot = 0;
-      bool have_prev = false, stop = false;
-      fetch_flags(slot);  // state after set-up (covers maxit <= 1 and an already converged x)
-      have_prev = true;
-      for (int64_t l = 0; l < max_launch && !stop; ++l) {
-        MI_HIP(hipGraphLaunch(ex, s));
-        const int prev = slot;
-        slot ^= 1;
+      const GraphKey pk{A, M, nvec, 0};
+      int &predicted = ws.predicted[pk];
+      const int64_t first = std::max<int64_t>(1, std::min<int64_t>(predicted > 0 ? predicted : ctx->chunk,
+                                                                  std::min<int64_t>(maxit, 1024)));
+      MI_HIP(hipGraphLaunch(graph(-(int)first), s));
+      enqueue_results(0);
+      MI_HIP(hipStreamSynchronize(s));
+      if (!ws.flags[0].done) {
+        hipGraphExec_t ex = graph(ctx->chunk);
+        const int64_t max_launch = (maxit + ctx->chunk - 1) / ctx->chunk + 2;
+        int slot = 0;
+        bool stop = false;
         fetch_flags(slot);
-        if (have_prev) {
+        for (int64_t l = 0; l < max_launch && !stop; ++l) {
+          MI_HIP(hipGraphLaunch(ex, s));
+          const int prev = slot;
+          slot ^= 1;
+          fetch_flags(slot);
           MI_HIP(hipEventSynchronize(ws.ev[prev]));
           stop = ws.flags[prev].done != 0;
         }
+        enqueue_results(0);
+        MI_HIP(hipStreamSynchronize(s));
       }
+      predicted = (int)std::max<long long>(1, ws.flags[0].it - 1);
     } else {
-      for (int64_t l = 0; l < max_launch; ++l) {
+      setup_tail();
+      for (int64_t l = 0; l < maxit + 2; ++l) {
         fetch_flags(0);
         MI_HIP(hipEventSynchronize(ws.ev[0]));
         if (ws.flags[0].done) break;
         iteration();
       }
+      enqueue_results(0);
+      MI_HIP(hipStreamSynchronize(s));
     }
-    MI_HIP(hipStreamSynchronize(s));
-    fetch_flags(0);
-    MI_HIP(hipStreamSynchronize(s));
     const long long it = ws.flags[0].it;
     if (!ws.flags[0].done) raise(MI_ERR_HIP, "internal: Krylov loop ended without the stop flag (it=%lld)", it);
-    MI_HIP(hipMemcpyAsync(x_io, ws.x.p, vb, hipMemcpyDeviceToDevice, s));
-    const int64_t ncopy = std::min<int64_t>(std::min<int64_t>(it, res_cap), cap_dev);
-    if (res_host && ncopy > 0)
-      MI_HIP(hipMemcpyAsync(res_host, ws.res_norm.p, sizeof(double) * ncopy, hipMemcpyDeviceToHost, s));
-    MI_HIP(hipStreamSynchronize(s));
+    const int64_t ncopy = std::min<int64_t>(it, ncap);
+    if (res_host && ncopy > 0) {
+      if (spec_res) std::memcpy(res_host, ws.res_stage, sizeof(double) * ncopy);
+      else {
+        MI_HIP(hipMemcpyAsync(res_host, ws.res_norm.p, sizeof(double) * ncopy, hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+      }
+    }
     if (it_out) *it_out = it;
     if (ws.flags[0].overflow || it > res_cap)
       return fail(MI_ERR_RES_CAPACITY, "res_norm capacity %lld < it = %lld", (long long)res_cap, it);

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Print the kernel timeline (start, duration, gap) of the last N `mi::` dispatches of a
+rocprofv3 --kernel-trace CSV, plus per-kernel averages over non-trivial (>1 us) dispatches."""
+import csv
+import sys
+from collections import defaultdict
+
+path, last = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 80
+rows = [r for r in csv.DictReader(open(path)) if "mi::" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+agg = defaultdict(list)
+for r in rows:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(d)
+print("kernel, calls, calls>1us, avg_ns(>1us), avg_ns(all)")
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+    big = [d for d in v if d > 1000]
+    print(f"{k:45s} {len(v):6d} {len(big):6d} {sum(big) / max(1, len(big)):10.0f} {sum(v) / len(v):10.0f}")
+t = rows[-last:]
+t0 = int(t[0]["Start_Timestamp"])
+prev = None
+for r in t:
+    s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+    gap = s - prev if prev is not None else 0
+    print(f"{s / 1e3:9.1f} us dur {(e - s) / 1e3:7.2f} gap {gap / 1e3:7.2f}  {r['Kernel_Name'].split('(')[0].replace('void mi::', '')}")
+    prev = e

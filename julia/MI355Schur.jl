@@ -1,0 +1,213 @@
+# MI355Schur.jl — the reference-side binding of libmi355schur (include/mi355schur.h).
+#
+# Drop this module next to Fem/ and RecyclingKrylovSolvers/ of venkovic/julia-phd-krylov-spdes and
+# `push!(LOAD_PATH, "./MI355Schur/")`. It is purely mechanical: every function is one `ccall`.
+# It exports the reference's own names for the hot path, so Example03/07-style scripts change only
+# the lines that BUILD the operators (see INTEGRATION.md); `pcg`/`defpcg` calls stay as they are.
+#
+# NOTE: there is no `julia` in the build container, so this file has been reviewed, not executed.
+module MI355Schur
+
+using LinearAlgebra
+using SparseArrays: SparseMatrixCSC
+import Base: *, \, size
+import LinearAlgebra: mul!, ldiv!
+
+export MiContext, MiOperator, MiPrecond,
+       LocalSchurs, MatrixFreeLocalSchurs, GlobalSchur, NeumannNeumannSchurPreconditioner,
+       apply_local_schurs, apply_global_schur, apply_neumann_neumann_schur,
+       cg, pcg, defcg, defpcg
+
+const lib = get(ENV, "MI355SCHUR_LIB", "libmi355schur")
+const MI_ERR_SINGULAR = Cint(-3)
+const MI_ERR_RES_CAPACITY = Cint(-4)
+
+function check(rc::Cint)
+  rc == 0 && return
+  msg = unsafe_string(ccall((:mi_last_error, lib), Cstring, ()))
+  rc == MI_ERR_SINGULAR && throw(LinearAlgebra.SingularException(0))   # `WtAW \ mu`, defcg.jl:53,273
+  rc == MI_ERR_RES_CAPACITY && throw(BoundsError())                    # res_norm[it], cg.jl:47
+  error("libmi355schur error $rc: $msg")
+end
+
+mutable struct MiContext
+  h::Ptr{Cvoid}
+  function MiContext(device::Integer=0)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mi_ctx_create, lib), Cint, (Cint, Ref{Ptr{Cvoid}}), device, r))
+    ctx = new(r[])
+    finalizer(c -> ccall((:mi_ctx_destroy, lib), Cint, (Ptr{Cvoid},), c.h), ctx)
+  end
+end
+
+# Anything usable as `A` (A*x, mul!) or as `M` (M \ r, ldiv!). `keep` roots Julia callbacks.
+mutable struct MiOperator
+  h::Ptr{Cvoid}
+  n::Int
+  N::Int            # LinearMaps.FunctionMap field read by Example07:273 (`S.N`)
+  ctx::MiContext
+  keep::Any
+end
+const MiPrecond = MiOperator
+
+function wrap(ctx::MiContext, r::Ref{Ptr{Cvoid}}, keep=nothing)
+  n = Ref{Int64}(0)
+  check(ccall((:mi_op_size, lib), Cint, (Ptr{Cvoid}, Ref{Int64}), r[], n))
+  op = MiOperator(r[], n[], n[], ctx, keep)
+  finalizer(o -> ccall((:mi_op_destroy, lib), Cint, (Ptr{Cvoid},), o.h), op)
+end
+
+size(A::MiOperator) = (A.n, A.n)
+
+function mul!(y::Vector{Float64}, A::MiOperator, x::Vector{Float64})     # cg.jl:36,93
+  check(ccall((:mi_op_apply, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), A.h, x, y))
+  y
+end
+*(A::MiOperator, x::Vector{Float64}) = mul!(Vector{Float64}(undef, A.n), A, x)   # cg.jl:28,83
+\(M::MiOperator, r::Vector{Float64}) = M * r                                     # EPDD.jl:1389-1392
+ldiv!(z::Vector{Float64}, M::MiOperator, r::Vector{Float64}) = mul!(z, M, r)     # EPDD.jl:1394-1398
+ldiv!(M::MiOperator, r::Vector{Float64}) = (r .= M * copy(r))                    # EPDD.jl:1400-1403
+
+# ---------------------------------------------------------------- flattening of the reference's containers
+# ind_Γd_Γ2l[d]::Dict{Int,Int} (lΓ => lΓd, EPDD.jl:186-191)  ->  gather_idx[d][lΓd] = lΓ (1-based kept;
+# the library is told index_base = 1).
+function flatten_maps(ind_Γd_Γ2l::Vector{Dict{Int,Int}})
+  g = [Vector{Int64}(undef, length(m)) for m in ind_Γd_Γ2l]
+  for (d, m) in enumerate(ind_Γd_Γ2l), (lΓ, lΓd) in m
+    g[d][lΓd] = lΓ
+  end
+  g
+end
+ptrs(v::Vector{<:Vector{T}}) where {T} = Ptr{T}[pointer(a) for a in v]
+
+"""`LocalSchurs(ctx, Sd, ind_Γd_Γ2l, node_Γ_cnt)`: the operator `x -> apply_local_schurs(Sd, ind_Γd_Γ2l,
+node_Γ_cnt, x)` (EPDD.jl:761-785) that Example03:131-135 wraps in a LinearMap."""
+function LocalSchurs(ctx::MiContext, Sd::Vector, ind_Γd_Γ2l::Vector{Dict{Int,Int}}, node_Γ_cnt::Vector{Int};
+                     dom_range=(0, length(Sd)))
+  ndom = length(Sd); g = flatten_maps(ind_Γd_Γ2l); nd = Int64[length(x) for x in g]
+  blocks = [Matrix{Float64}(S) for S in Sd]              # `Array(Sd[idom])`, column-major
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve g blocks begin
+    check(ccall((:mi_schur_assembled_create, lib), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Cint, Int64, Int64, Ref{Ptr{Cvoid}}),
+                ctx.h, ndom, length(node_Γ_cnt), nd, ptrs(g), Ptr{Float64}[pointer(b) for b in blocks], 1,
+                dom_range[1], dom_range[2], r))
+  end
+  wrap(ctx, r)
+end
+
+"""`NeumannNeumannSchurPreconditioner(ctx, ΠSd, ind_Γd_Γ2l, node_Γ_cnt)` (EPDD.jl:1111-1137)."""
+function NeumannNeumannSchurPreconditioner(ctx::MiContext, ΠSd::Vector{Matrix{Float64}},
+                                           ind_Γd_Γ2l::Vector{Dict{Int,Int}}, node_Γ_cnt::Vector{Int};
+                                           dom_range=(0, length(ΠSd)))
+  ndom = length(ΠSd); g = flatten_maps(ind_Γd_Γ2l); nd = Int64[length(x) for x in g]
+  cnt = Vector{Int64}(node_Γ_cnt)
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve g ΠSd cnt begin
+    check(ccall((:mi_nn_create, lib), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Cint, Int64, Int64, Ref{Ptr{Cvoid}}),
+                ctx.h, ndom, length(cnt), nd, ptrs(g), Ptr{Float64}[pointer(b) for b in ΠSd], cnt, 1,
+                dom_range[1], dom_range[2], r))
+  end
+  wrap(ctx, r)
+end
+
+# Interior solve callback: `interior(idom, rhs) -> A_II[idom] \ rhs`, e.g. a CHOLMOD factor or
+# `rhs -> IterativeSolvers.cg(A_IIdd[idom], rhs, Pl=Π_IId[idom], reltol=1e-9)` (EPDD.jl:648-650).
+function interior_trampoline(user::Ptr{Cvoid}, idom::Int64, n::Int64, rhs::Ptr{Float64}, sol::Ptr{Float64})::Cint
+  f = unsafe_pointer_to_objref(user)[]
+  try
+    unsafe_wrap(Array, sol, n) .= f(Int(idom) + 1, copy(unsafe_wrap(Array, rhs, n)))
+    return Cint(0)
+  catch
+    return Cint(1)
+  end
+end
+
+csc_parts(As::Vector{SparseMatrixCSC{Float64,Int}}) =
+  ([Vector{Int64}(A.colptr) for A in As], [Vector{Int64}(A.rowval) for A in As], [A.nzval for A in As])
+
+"""`MatrixFreeLocalSchurs(ctx, A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γd_Γ2l, node_Γ_cnt, interior)`: the operator of
+Example03:143-150, `apply_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, ...)` (EPDD.jl:711-747); sparse products on the
+GPU, `A_IIdd^{-1}` through `interior(idom, rhs)` on the host."""
+function MatrixFreeLocalSchurs(ctx::MiContext, A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γd_Γ2l, node_Γ_cnt, interior)
+  ndom = length(A_IΓdd); g = flatten_maps(ind_Γd_Γ2l)
+  nd = Int64[length(x) for x in g]; ni = Int64[A.n for A in A_IIdd]
+  igp, igi, igv = csc_parts(A_IΓdd); ggp, ggi, ggv = csc_parts(A_ΓΓdd)
+  fref = Ref{Any}(interior)
+  cb = @cfunction(interior_trampoline, Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}))
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve g igp igi igv ggp ggi ggv fref begin
+    check(ccall((:mi_schur_matfree_create, lib), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Ptr{Int64}},
+                 Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}},
+                 Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Int64, Ref{Ptr{Cvoid}}),
+                ctx.h, ndom, length(node_Γ_cnt), nd, ni, ptrs(g), ptrs(igp), ptrs(igi), ptrs(igv),
+                ptrs(ggp), ptrs(ggi), ptrs(ggv), cb, pointer_from_objref(fref), 1, 0, ndom, r))
+  end
+  wrap(ctx, r, (fref, cb))
+end
+
+"""`GlobalSchur(ctx, A_IId, A_IΓd, A_ΓΓ, interior)`: `x -> apply_global_schur(A_IId, A_IΓd, A_ΓΓ, x)`
+(EPDD.jl:596-625), the operator of Example03:101."""
+function GlobalSchur(ctx::MiContext, A_IId, A_IΓd, A_ΓΓ::SparseMatrixCSC{Float64,Int}, interior)
+  ndom = length(A_IΓd); ni = Int64[A.n for A in A_IId]
+  igp, igi, igv = csc_parts(A_IΓd)
+  ggp, ggi = Vector{Int64}(A_ΓΓ.colptr), Vector{Int64}(A_ΓΓ.rowval)
+  fref = Ref{Any}(interior)
+  cb = @cfunction(interior_trampoline, Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}))
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve igp igi igv ggp ggi fref begin
+    check(ccall((:mi_schur_global_create, lib), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}},
+                 Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}),
+                ctx.h, ndom, A_ΓΓ.n, ni, ptrs(igp), ptrs(igi), ptrs(igv), ggp, ggi, A_ΓΓ.nzval,
+                cb, pointer_from_objref(fref), 1, r))
+  end
+  wrap(ctx, r, (fref, cb))
+end
+
+"""A symmetric `SparseMatrixCSC` as a device operator (config 2: `pcg(A, b, x, M)` on the full system)."""
+function MiOperator(ctx::MiContext, A::SparseMatrixCSC{Float64,Int})
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  cp, rv = Vector{Int64}(A.colptr), Vector{Int64}(A.rowval)
+  check(ccall((:mi_csr_create, lib), Cint,
+              (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint, Ref{Ptr{Cvoid}}),
+              ctx.h, A.m, A.n, cp, rv, A.nzval, 1, r))
+  wrap(ctx, r)
+end
+
+# reference-named free functions (EPDD.jl:711, 761, 596, 1361)
+apply_local_schurs(S::MiOperator, x::Vector{Float64}) = S * x
+apply_global_schur(S::MiOperator, x::Vector{Float64}) = S * x
+apply_neumann_neumann_schur(Πnn::MiOperator, r::Vector{Float64}) = Πnn * r
+
+# ---------------------------------------------------------------- solver drop-ins (whole loop on the GPU)
+# Same positional order, keyword and 3-tuple return as RecyclingKrylovSolvers (cg.jl:14,67; defcg.jl:24,242).
+function solve(sym::Symbol, A::MiOperator, M, b::Vector{Float64}, x::Vector{Float64}, W, maxit::Int)
+  n = A.n
+  res = Vector{Float64}(undef, n)                      # cg.jl:23 `res_norm = Array{T,1}(undef, n)`
+  it = Ref{Int64}(0)
+  rc = if sym == :cg
+    ccall((:mi_cg, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Ptr{Float64}, Int64, Ref{Int64}),
+          A.h, b, x, maxit, 1e-7, res, n, it)
+  elseif sym == :pcg
+    ccall((:mi_pcg, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Ptr{Float64}, Int64, Ref{Int64}),
+          A.h, M.h, b, x, maxit, 1e-7, res, n, it)
+  elseif sym == :defcg
+    ccall((:mi_defcg, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Float64, Ptr{Float64}, Int64, Ref{Int64}),
+          A.h, b, x, W, size(W, 2), maxit, 1e-7, res, n, it)
+  else
+    ccall((:mi_defpcg, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Float64, Ptr{Float64}, Int64, Ref{Int64}),
+          A.h, M.h, b, x, W, size(W, 2), maxit, 1e-7, res, n, it)
+  end
+  check(rc)
+  return x, Int(it[]), res[1:it[]]
+end
+
+cg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}; maxit=0) = solve(:cg, A, nothing, b, x, nothing, maxit)
+pcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, M::MiOperator; maxit=0) = solve(:pcg, A, M, b, x, nothing, maxit)
+defcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, W::Matrix{Float64}; maxit=0) = solve(:defcg, A, nothing, b, x, W, maxit)
+defpcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, W::Matrix{Float64}, M::MiOperator; maxit=0) = solve(:defpcg, A, M, b, x, W, maxit)
+
+end # module

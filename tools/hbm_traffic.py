@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-launch HBM-side traffic of the
+dominant kernels and write profiles/hbm_traffic.json (read by bench.py for roofline.traffic).
+
+Units and corrections follow /opt/skills/guides (MI355X_MICROARCH.md §HBM, cdna_hip_programming.md §7):
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide
+coalesced streaming read (16 B/lane), so the read side is doubled; WRITE_SIZE is exact. Infinity-Cache
+hits are counted (the counters sit on the L2's memory side), so this is L2-miss traffic.
+
+    python tools/hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") != counter:
+            continue
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    res = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB -> bytes; "
+                     "FETCH_SIZE x2 (gfx950 wide-read correction); median over dispatches that do work"}
+    for k in sorted(f):
+        if "mi::" not in k:
+            continue
+        fv = sorted(v for v in f[k])
+        wv = sorted(v for v in w.get(k, [0.0]))
+        # launches that return at once (stop flag) fetch ~nothing: take the upper half's median
+        fm = fv[len(fv) * 3 // 4] if fv else 0.0
+        wm = wv[len(wv) * 3 // 4] if wv else 0.0
+        res[k] = {"dispatches": len(fv), "fetch_KiB_raw": fm, "write_KiB_raw": wm,
+                  "bytes_per_launch": int((2.0 * fm + wm) * 1024)}
+    s = res.get("mi::k_gemv_batched<2, false, 0>")
+    if s:
+        res["k_gemv_batched_S_bytes_per_launch"] = s["bytes_per_launch"]
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -19,6 +19,7 @@ struct SolverState {
   double d, alpha, beta;      // diagnostics (each workgroup recomputes them from the partials)
   double tol, bnorm, eps;
   long long it, maxit, res_cap;
+  long long it_nxt;           // folded PCG: iteration counter written one launch ahead of `it`
   int done;
   int overflow;               // res_norm capacity hit (BoundsError in the reference)
 };
@@ -42,6 +43,23 @@ __device__ __forceinline__ double block_sum(double v, double *sm) {
   }
   __syncthreads();
   const double t = sm[NT / 64];
+  __syncthreads();
+  return t;
+}
+// The same for a workgroup of NTH threads (the GEMV kernels run with 256 or 512).
+template <int NTH>
+__device__ __forceinline__ double block_sum_t(double v, double *sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < NTH / 64; ++i) t += sm[i];
+    sm[NTH / 64] = t;
+  }
+  __syncthreads();
+  const double t = sm[NTH / 64];
   __syncthreads();
   return t;
 }
@@ -173,7 +191,6 @@ __device__ __forceinline__ void gemv_load_group(double2 (&mv)[RPW][4], const dou
       mv[k][u] = (c < pw) ? *reinterpret_cast<const double2 *>(rowp[k] + col0 + c) : make_double2(0.0, 0.0);
   }
 }
-
 template <int RPW>
 __device__ __forceinline__ void gemv_fma_group(double (&acc)[RPW], const double2 (&mv)[RPW][4], const double *xs, int cb,
                                                int pw, int lane) {
@@ -188,34 +205,56 @@ __device__ __forceinline__ void gemv_fma_group(double (&acc)[RPW], const double2
     }
   }
 }
+// Row streamer of one tile: RPW rows per wave, 16 B per lane and row per load, groups of 4 loads.
+// `begin` issues the first group of matrix loads (so the stream is in flight while the caller
+// stages the column values into LDS), `panel` consumes one staged panel, `finish` reduces.
+template <int RPW>
+struct GemvRows {
+  const double *rowp[RPW];
+  double acc[RPW];
+  double2 buf[RPW][4];
+  int lane, ld;
+  __device__ __forceinline__ void begin(const DenseMeta &m, const GemvTile &t) {
+    lane = threadIdx.x & 63;
+    ld = t.ld;
+    const int row_base = t.row0 + (threadIdx.x >> 6) * RPW;
+    const double *Md = m.M + t.mat_off;
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int r = min(row_base + k, t.n - 1);  // clamp: tail rows re-read a valid row, result dropped
+      rowp[k] = Md + (long long)r * ld;
+      acc[k] = 0.0;
+    }
+    gemv_load_group<RPW>(buf, rowp, 0, 0, min(GEMV_PANEL, ld), lane);
+  }
+  // xs holds columns [c0, c0 + pw) of the operand; for c0 > 0 the first group is loaded here
+  __device__ __forceinline__ void panel(const double *xs, int c0, int pw) {
+    if (c0) gemv_load_group<RPW>(buf, rowp, c0, 0, pw, lane);
+    for (int cb = 0; cb < pw; cb += 512) {
+      if (cb) gemv_load_group<RPW>(buf, rowp, c0, cb, pw, lane);
+      gemv_fma_group<RPW>(acc, buf, xs, cb, pw, lane);
+    }
+  }
+  __device__ __forceinline__ void finish(double (&sum)[RPW]) {
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) sum[k] = wave_sum(acc[k]);  // valid in lane 0
+  }
+};
 
-template <int RPW, bool SCALE, int PIPE>  // PIPE 1: two load groups in flight (ping-pong); 0: one
-__global__ __launch_bounds__(NT) void k_gemv_batched(DenseMeta m, const double *__restrict__ x,
-                                                     double *__restrict__ yslots, const int *done) {
+template <int RPW, bool SCALE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_gemv_batched(DenseMeta m, const double *__restrict__ x,
+                                                             double *__restrict__ yslots, const int *done) {
+  constexpr int NTH = 64 * WAVES;
   if (done && *done) return;
   __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
   const GemvTile t = m.tiles[blockIdx.x];
-  const int n = t.n, ld = t.ld, off = t.loc_off;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int row_base = t.row0 + w * RPW;
-  const double *Md = m.M + t.mat_off;
-  const double *rowp[RPW];
-  double acc[RPW];
-#pragma unroll
-  for (int k = 0; k < RPW; ++k) {
-    const int r = min(row_base + k, n - 1);  // clamp: tail rows re-read a valid row, result dropped
-    rowp[k] = Md + (long long)r * ld;
-    acc[k] = 0.0;
-  }
-  double2 bufA[RPW][4], bufB[RPW][4];
-  gemv_load_group<RPW>(bufA, rowp, 0, 0, min(GEMV_PANEL, ld), lane);  // in flight during the gather below
-  for (int c0 = 0; c0 < ld; c0 += GEMV_PANEL) {
-    const int pw = min(GEMV_PANEL, ld - c0);  // multiple of 16
-    if (c0) {
-      __syncthreads();
-      gemv_load_group<RPW>(bufA, rowp, c0, 0, pw, lane);
-    }
-    for (int l = threadIdx.x; l < pw; l += NT) {
+  const int off = t.loc_off, n = t.n;
+  GemvRows<RPW> rows;
+  rows.begin(m, t);
+  for (int c0 = 0; c0 < t.ld; c0 += GEMV_PANEL) {
+    const int pw = min(GEMV_PANEL, t.ld - c0);  // multiple of 16
+    if (c0) __syncthreads();
+    for (int l = threadIdx.x; l < pw; l += NTH) {
       const int j = c0 + l;
       double v = 0.0;
       if (j < n) {
@@ -225,26 +264,241 @@ __global__ __launch_bounds__(NT) void k_gemv_batched(DenseMeta m, const double *
       xs[l] = v;
     }
     __syncthreads();
-    if (PIPE) {
-      // ping-pong: two groups of 4 x 16 B per lane and row in flight; loads past pw are predicated off
-      for (int cb = 0; cb < pw; cb += 1024) {
-        gemv_load_group<RPW>(bufB, rowp, c0, cb + 512, pw, lane);
-        gemv_fma_group<RPW>(acc, bufA, xs, cb, pw, lane);
-        gemv_load_group<RPW>(bufA, rowp, c0, cb + 1024, pw, lane);
-        gemv_fma_group<RPW>(acc, bufB, xs, cb + 512, pw, lane);
-      }
-    } else {
-      for (int cb = 0; cb < pw; cb += 512) {
-        if (cb) gemv_load_group<RPW>(bufA, rowp, c0, cb, pw, lane);
-        gemv_fma_group<RPW>(acc, bufA, xs, cb, pw, lane);
+    rows.panel(xs, c0, pw);
+  }
+  double sum[RPW];
+  rows.finish(sum);
+  const int row_base = t.row0 + (threadIdx.x >> 6) * RPW;
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int r = row_base + k;
+    if (rows.lane == 0 && r < n) yslots[m.out_pos[off + r]] = SCALE ? sum[k] / m.cnt[off + r] : sum[k];
+  }
+}
+
+// ------------------------------------------------------------------ PCG folded into the two GEMVs (2 launches / iteration)
+// For pcg(S, b, x, ΠSnn) with both operators dense and built on the same subdomain maps, the vector
+// work of an iteration is folded into the prologue/epilogue of the two GEMV launches:
+//
+//   PHASE 1 (ΠS GEMV): d = Σ partial(p'Ap); alpha = r'z / d (cg.jl:94-95); r_new = r - alpha Ap for this
+//            workgroup's columns (Ap = Γ-sum of the S contributions) -> LDS, scaled by 1/cnt; the workgroup that
+//            owns a Γ node (first contributing subdomain) stores r_new, x += alpha p (cg.jl:97-98); GEMV;
+//            epilogue: z contributions, partial r'z and partial r'r (cg.jl:99-101).
+//   PHASE 0 (S GEMV):  r'r, r'z from the partials; it += 1; res_norm[it] = sqrt(r'r); stop rule (cg.jl:91,
+//            104-105) — evaluated identically by every workgroup; beta = (1/old)*new; p_new = beta p + z for this
+//            workgroup's columns (z = Γ-sum of the ΠS contributions) -> LDS (cg.jl:102-103); owners store p_new;
+//            GEMV; epilogue: S contributions, partial p'Ap (cg.jl:93-94).
+//
+// A dot product is therefore summed per GEMV row and then over tiles (Σ_d Σ_rows p_g y_row = Σ_g p_g Σ_d y),
+// a re-association of the same terms.
+// Everything the prologue reads is kept in LOCAL order (one entry per (subdomain, Γ_d slot)), so the
+// loads of a workgroup are contiguous and need no index chain: a producer writes its row result
+// into the contribution row of every subdomain that shares the Γ node (`tgt`, <= W tiny stores), and
+// the owner of a node writes the updated vector entry into every sharing subdomain's copy (`peer`).
+// r and p have a "current" copy (read by everyone) and a "next" copy (written by owners); the owners
+// of the following launch copy next -> current, so no launch reads a buffer it writes. Scalars follow
+// the same rule (it/it_nxt, rTz/rTz_prev).
+// Start-up: it_nxt = 0 marks the first PHASE 1 launch (alpha = 0, so r_new = r_0 and x is untouched;
+// p = 0 and rTz_prev = 1 make the first PHASE 0 produce p = z_0, it = 1, res_norm[1] = ||r_0||).
+struct PcgFold {
+  SolverState *st;
+  const double *con_in;     // [nloc*W] contributions to sum: S (PHASE 1) / ΠS (PHASE 0), local order
+  double *con_out;          // [nloc*W]
+  const double *part_in0;   // PHASE 1: partial p'Ap         PHASE 0: partial r'r
+  const double *part_in1;   //                               PHASE 0: partial r'z
+  int n_in;
+  double *part_out0;        // PHASE 1: partial r'r          PHASE 0: partial p'Ap
+  double *part_out1;        // PHASE 1: partial r'z
+  double *r_cur, *r_nxt, *p_cur, *p_nxt;  // [nloc] local-order copies
+  double *x;                // [n_Γ]
+  const double *r_gamma;    // [n_Γ] r_0 in Γ order: the first PHASE 1 launch gathers it (no separate scatter pass)
+  double *res_norm;
+  const int *tgt;           // [nloc*W] where this row's result goes in each sharing subdomain's contribution row (-1 pad)
+  const int *peer;          // [nloc*W] local positions of the same Γ node in the sharing subdomains (-1 pad)
+  const int *jrank;         // [nloc] rank of this subdomain among the contributors of the node (0 = owner)
+  int W;
+};
+__device__ __forceinline__ double slot_sum(const double *slots, int g, int W) {
+  double s = 0.0;
+  if (W == 4) {
+    const double4 q = *reinterpret_cast<const double4 *>(slots + 4ll * g);
+    s += q.x; s += q.y; s += q.z; s += q.w;
+  } else if (W == 2) {
+    const double2 q = *reinterpret_cast<const double2 *>(slots + 2ll * g);
+    s += q.x; s += q.y;
+  } else {
+    for (int j = 0; j < W; ++j) s += slots[(long long)g * W + j];
+  }
+  return s;
+}
+
+// FOLD_CPT = columns per thread staged in registers: the launch needs max n_Γd <= FOLD_CPT * 256 (<= GEMV_PANEL)
+// FOLD_CPT = columns per thread staged in registers: the launch needs max n_Γd <= FOLD_CPT * 64 * WAVES (<= GEMV_PANEL)
+template <int RPW, int PHASE, int FOLD_CPT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f) {
+  constexpr int NTH = 64 * WAVES, NR = WAVES * RPW;  // threads and rows per workgroup
+  SolverState *st = f.st;
+  if (st->done) return;
+  __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
+  __shared__ double sm[NTH / 64 + 1];
+  __shared__ double rowv[NR], rowc0[NR], rowc1[NR];
+  const GemvTile t = m.tiles[blockIdx.x];
+  const int off = t.loc_off, W = f.W, n = t.n;
+  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  GemvRows<RPW> rows;
+  rows.begin(m, t);  // matrix stream in flight from here on
+
+  // ---- every load of the prologue is issued before the first barrier (one memory round trip), all contiguous
+  const long long it0 = st->it, it_nxt0 = st->it_nxt, maxit = st->maxit, cap = st->res_cap;
+  const double tol = st->tol, rTz0 = st->rTz, old = st->rTz_prev;
+  const bool first1 = PHASE == 1 && it_nxt0 == 0;  // very first launch of a solve: r_0 comes from the Γ-ordered vector, p = 0
+  double pa = 0.0, pb = 0.0;
+  for (int i = threadIdx.x; i < f.n_in; i += NTH) {
+    pa += f.part_in0[i];
+    if (PHASE == 0) pb += f.part_in1[i];
+  }
+  double cv[FOLD_CPT], cs[FOLD_CPT], cc[FOLD_CPT];  // vector value, Γ-sum of the contributions, cnt — per column
+#pragma unroll
+  for (int q = 0; q < FOLD_CPT; ++q) {
+    const int j = q * NTH + threadIdx.x;
+    cv[q] = cs[q] = 0.0; cc[q] = 1.0;
+    if (j < n) {
+      const int loc = off + j;
+      cs[q] = slot_sum(f.con_in, loc, W);
+      if (PHASE == 1) { cv[q] = first1 ? f.r_gamma[m.gidx[loc]] : f.r_cur[loc]; cc[q] = m.cnt[loc]; }
+      else cv[q] = f.p_cur[loc];
+    }
+  }
+  // The thread whose column j is also a row of this tile serves that row (at most one column per thread:
+  // the 4*RPW rows are consecutive). Its owner duties need p/r of the node, x[g] and the peer list: load now.
+  int o_q = -1, o_g = 0;
+  bool o_own = false;
+  double o_a = 0.0, o_x = 0.0;  // PHASE 1: p (next copy), x[g]    PHASE 0: r (next copy)
+  int o_peer[4] = {-1, -1, -1, -1};
+#pragma unroll
+  for (int q = 0; q < FOLD_CPT; ++q) {
+    const int j = q * NTH + threadIdx.x, ri = j - t.row0;
+    if (j < n && ri >= 0 && ri < NR) {
+      const int loc = off + j;
+      o_q = q;
+      o_own = f.jrank[loc] == 0;
+      if (o_own) {
+        if (PHASE == 1) { o_a = first1 ? 0.0 : f.p_nxt[loc]; o_g = m.gidx[loc]; o_x = f.x[o_g]; }
+        else o_a = f.r_nxt[loc];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < W) o_peer[k] = f.peer[loc * W + k];
       }
     }
   }
+  // lane 0 of every wave stores the results of its RPW rows into the contribution rows of all sharing subdomains
+  int e_tgt[RPW][4];
+  double e_cnt[RPW];
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
-    const double sum = wave_sum(acc[k]);
-    const int r = row_base + k;
-    if (lane == 0 && r < n) yslots[m.out_pos[off + r]] = SCALE ? sum / m.cnt[off + r] : sum;
+    const int r = t.row0 + (int)(threadIdx.x >> 6) * RPW + k;
+    e_cnt[k] = 1.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e_tgt[k][q] = -1;
+    if ((threadIdx.x & 63) == 0 && r < n) {
+      const int loc = off + r;
+      if (PHASE == 1) e_cnt[k] = m.cnt[loc];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (q < W) e_tgt[k][q] = f.tgt[loc * W + q];
+    }
+  }
+
+  // ---- scalars
+  double coef;  // alpha (PHASE 1) or beta (PHASE 0)
+  if (PHASE == 1) {
+    const bool first = first1;
+    const double d = block_sum_t<NTH>(pa, sm);
+    coef = first ? 0.0 : rTz0 / d;
+    if (lead) {
+      st->d = d; st->alpha = coef;
+      st->rTz_prev = first ? 1.0 : rTz0;
+      st->it = it_nxt0;
+    }
+  } else {
+    const long long it_new = it0 + 1;
+    const double rr = block_sum_t<NTH>(pa, sm);
+    const double rz = block_sum_t<NTH>(pb, sm);
+    const double res = sqrt(rr);
+    const bool stop = !((it_new < maxit) && (res > tol));
+    coef = 1. / old;
+    coef *= rz;
+    if (lead) {
+      st->rTr = rr; st->rTz = rz; st->beta = coef;
+      st->it_nxt = it_new;
+      if (it_new <= cap) f.res_norm[it_new - 1] = res; else st->overflow = 1;
+      if (stop) st->done = 1;
+    }
+    if (stop) return;  // same decision in every workgroup
+  }
+
+  // ---- operand of this GEMV into LDS; rows of this tile: value for the epilogue dot, owners' stores
+  if (threadIdx.x < NR) { rowc0[threadIdx.x] = 0.0; rowv[threadIdx.x] = 0.0; }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < FOLD_CPT; ++q) {
+    const int j = q * NTH + threadIdx.x;
+    if (j < t.ld) {
+      double v = 0.0, vs = 0.0;
+      if (j < n) {
+        v = PHASE == 1 ? cv[q] + (-coef) * cs[q]          // r - alpha*Ap
+                       : coef * cv[q] + cs[q];            // beta*p + z
+        vs = PHASE == 1 ? v / cc[q] : v;
+      }
+      xs[j] = vs;
+      if (q == o_q) {
+        const int ri = j - t.row0;
+        rowv[ri] = v;
+        if (o_own) {                                      // owner of this Γ node
+          if (PHASE == 1) {
+            f.x[o_g] = o_x + coef * o_a;                  // x + alpha*p
+            rowc0[ri] = v * v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int pl = o_peer[k];
+              if (pl >= 0) { f.r_nxt[pl] = v; f.p_cur[pl] = o_a; }
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int pl = o_peer[k];
+              if (pl >= 0) { f.p_nxt[pl] = v; f.r_cur[pl] = o_a; }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  rows.panel(xs, 0, t.ld);
+  double sum[RPW];
+  rows.finish(sum);
+  const int w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int ri = w * RPW + k, r = t.row0 + ri;
+    if (rows.lane == 0) {
+      double y = 0.0;
+      if (r < n) {
+        y = PHASE == 1 ? sum[k] / e_cnt[k] : sum[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int tg = e_tgt[k][q];
+          if (tg >= 0) f.con_out[tg] = y;
+        }
+      }
+      rowc1[ri] = (r < n ? rowv[ri] : 0.0) * y;    // r_g * z-contribution  /  p_g * Ap-contribution
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < NR; ++i) { a += rowc1[i]; b += rowc0[i]; }
+    if (PHASE == 1) { f.part_out1[blockIdx.x] = a; f.part_out0[blockIdx.x] = b; }
+    else f.part_out0[blockIdx.x] = a;
   }
 }
 
@@ -515,11 +769,14 @@ __global__ __launch_bounds__(NTF) void k_fused_p(int n, SolverState *st, AsmView
     st->done = !((it < maxit) && (res > tol));
   }
 }
-// Set-up, first half: r = b - A*x (Ap as a view); r'r and b'b   (cg.jl:28-29,32 / 83-84,88)
-template <int EPT>
+// Set-up, first half: r = b - A*x (Ap as a view); r'r and b'b   (cg.jl:28-29,32 / 83-84,88).
+// FOLD: also the scalars the folded PCG launches (k_gemv_pcg) expect at start-up: tol, it_nxt = 0,
+// rTz_prev = 1, flags cleared (the first PHASE 1 launch gathers r_0 and treats p as 0 by itself).
+template <int EPT, bool FOLD>
 __global__ __launch_bounds__(NTF) void k_fused_residual(int n, SolverState *st, AsmView vAp,
                                                         const double *__restrict__ b, double *__restrict__ r) {
   __shared__ double sm[NTF / 64 + 1];
+  const double eps = st->eps;
   double srr = 0.0, sbb = 0.0;
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
@@ -534,7 +791,15 @@ __global__ __launch_bounds__(NTF) void k_fused_residual(int n, SolverState *st, 
   }
   srr = block_sum_f(srr, sm);
   sbb = block_sum_f(sbb, sm);
-  if (threadIdx.x == 0) { st->rTr = srr; st->bnorm = sqrt(sbb); }
+  if (threadIdx.x == 0) {
+    st->rTr = srr; st->bnorm = sqrt(sbb);
+    if (FOLD) {
+      st->tol = eps * st->bnorm;
+      st->it = 0; st->it_nxt = 0; st->done = 0; st->overflow = 0;
+      st->rTz = 0.0; st->rTz_prev = 1.0; st->rTr_prev = srr;
+      st->d = 0.0; st->alpha = 0.0; st->beta = 0.0;
+    }
+  }
 }
 // Set-up, second half: z = view; r'z; p = z; it = 1; res_norm[1]; tol; stop rule (cg.jl:26-33 / 81-89).
 // eps, maxit, res_cap arrive through st->tol / st->maxit / st->res_cap (written by the host before the

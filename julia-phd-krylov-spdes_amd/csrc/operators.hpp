@@ -24,6 +24,7 @@ inline int to_i32(int64_t v, int64_t lo, int64_t hi, const char *what) {
 }
 
 // ------------------------------------------------------------------ base class
+struct DenseBlockOp;
 struct Operator {
   mi_ctx_s *ctx;
   int64_t n;  // operator is n x n on the Γ (or full) vector space
@@ -37,6 +38,7 @@ struct Operator {
     apply(x, y, done);
     return AsmView{y, 0};
   }
+  virtual DenseBlockOp *as_dense() { return nullptr; }
   virtual bool graph_safe() const { return true; }  // false: apply synchronises with the host
   virtual void bytes(int64_t *apply_b, int64_t *dominant_b) const = 0;
   virtual void apply_dominant(const double *x) = 0;
@@ -168,6 +170,7 @@ struct LocalMaps {
   int nloc = 0;  // Σ n_Γd over local subdomains
   std::vector<int> nd, loc_off, gidx_h;
   DevBuf<int> gidx, aptr, apos, out_pos;
+  DevBuf<int> jrank, peer, tgt, gpeer;  // local-order bookkeeping of the folded PCG launches (kernels.hpp PcgFold)
   int slot_width = 1;  // W: contribution slots per Γ node (max multiplicity over this rank's subdomains)
   void build(mi_ctx_s *c, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d, const int64_t *const *gather_idx,
              int base, int64_t d0, int64_t d1) {
@@ -211,6 +214,25 @@ struct LocalMaps {
     for (int64_t i = 0; i < n_gamma; ++i)
       for (int k = cntv[i]; k < cntv[i + 1]; ++k) op[pos[k]] = (int)(i * slot_width + (k - cntv[i]));
     out_pos.upload(op, c->stream);
+    // folded PCG: for local position `loc` of Γ node g with contributors loc_0 < loc_1 < ... (ascending subdomain):
+    //   jrank[loc] = my rank among them; peer[loc*W+k] = loc_k; tgt[loc*W+k] = loc_k*W + jrank[loc];
+    //   gpeer[g*W+k] = loc_k
+    const int W = slot_width;
+    std::vector<int> jr(nloc), pe((size_t)nloc * W + 4, -1), tg((size_t)nloc * W + 4, -1), gp((size_t)n_gamma * W + 4, -1);
+    for (int64_t i = 0; i < n_gamma; ++i) {
+      const int m = cntv[i + 1] - cntv[i];
+      for (int a = 0; a < m; ++a) {
+        const int la = pos[cntv[i] + a];
+        jr[la] = a;
+        gp[(size_t)i * W + a] = la;
+        for (int k = 0; k < m; ++k) {
+          const int lk = pos[cntv[i] + k];
+          pe[(size_t)la * W + k] = lk;
+          tg[(size_t)la * W + k] = lk * W + a;
+        }
+      }
+    }
+    jrank.upload(jr, c->stream); peer.upload(pe, c->stream); tgt.upload(tg, c->stream); gpeer.upload(gp, c->stream);
   }
   void assemble(mi_ctx_s *c, int64_t n_gamma, const double *yloc, double *y, const int *done) const {
     hipLaunchKernelGGL(k_assemble, dim3(vec_grid(n_gamma)), dim3(NT), 0, c->stream, (int)n_gamma, aptr.p, apos.p, yloc,
@@ -224,8 +246,10 @@ struct LocalMaps {
 struct DenseBlockOp : Operator {
   LocalMaps maps;
   bool scale;  // true: Neumann-Neumann (gather r/cnt, result /cnt)
-  int rpw, pipe, ntiles = 0;
+  int rpw, waves, ntiles = 0, max_nd = 0;  // rows per wave, waves per workgroup (4 or 8)
   DevBuf<double> M, cnt, yslots;
+  DevBuf<double> fold_part0, fold_part1;  // per-tile partial dots of the folded PCG launches
+  DevBuf<double> fold_con, fold_vec;      // [nloc*W] local-order contributions; [4*nloc] r/p current+next copies
   DevBuf<GemvTile> tiles;
   int64_t alg_bytes = 0;
   DenseMeta meta{};
@@ -237,7 +261,8 @@ struct DenseBlockOp : Operator {
     maps.build(c, ndom, n_gamma, n_gamma_d, gather_idx, base, d0, d1);
     rpw = env_int("MI355_GEMV_RPW", 2);
     if (rpw != 1 && rpw != 2 && rpw != 4) rpw = 2;
-    pipe = env_int("MI355_GEMV_PIPE", 0) ? 1 : 0;
+    waves = env_int("MI355_GEMV_WAVES", 16);
+    if (waves != 4 && waves != 8 && waves != 16) waves = 16;
     std::vector<long long> moff;
     std::vector<int> ldv;
     std::vector<GemvTile> tv;
@@ -246,7 +271,8 @@ struct DenseBlockOp : Operator {
       const int n_d = maps.nd[dl], l = (n_d + 15) / 16 * 16;
       if (n_d && !blocks[d0 + dl]) raise(MI_ERR_BAD_ARG, "dense block %d is NULL", dl);
       moff.push_back(tot); ldv.push_back(l);
-      for (int r = 0; r < n_d; r += 4 * rpw) tv.push_back(GemvTile{tot, n_d, l, maps.loc_off[dl], r, 0, 0});
+      max_nd = std::max(max_nd, n_d);
+      for (int r = 0; r < n_d; r += waves * rpw) tv.push_back(GemvTile{tot, n_d, l, maps.loc_off[dl], r, 0, 0});
       tot += (long long)n_d * l;
       alg_bytes += 8ll * n_d * n_d + 16ll * n_d + 4ll * n_d;
     }
@@ -274,16 +300,21 @@ struct DenseBlockOp : Operator {
     tiles.upload(tv, c->stream);
     yslots.alloc((size_t)n_gamma * maps.slot_width + 4);
     yslots.zero(c->stream);  // unused slots stay 0 for the lifetime of the operator
+    fold_part0.alloc((size_t)ntiles + 1); fold_part1.alloc((size_t)ntiles + 1);
+    fold_part0.zero(c->stream); fold_part1.zero(c->stream);
+    fold_con.alloc((size_t)maps.nloc * maps.slot_width + 4); fold_con.zero(c->stream);
+    fold_vec.alloc((size_t)maps.nloc * 4 + 4); fold_vec.zero(c->stream);
     MI_HIP(hipStreamSynchronize(c->stream));
     meta = DenseMeta{M.p, tiles.p, maps.gidx.p, scale ? cnt.p : nullptr, maps.out_pos.p};
   }
   void gemv(const double *x, const int *done) {
     if (!ntiles) return;
-#define MI_GEMV(R, S, P) hipLaunchKernelGGL((k_gemv_batched<R, S, P>), dim3(ntiles), dim3(NT), 0, ctx->stream, meta, x, yslots.p, done)
-#define MI_GEMV_S(R, P) do { if (scale) MI_GEMV(R, true, P); else MI_GEMV(R, false, P); } while (0)
-    if (pipe) { if (rpw == 1) MI_GEMV_S(1, 1); else if (rpw == 2) MI_GEMV_S(2, 1); else MI_GEMV_S(4, 1); }
-    else      { if (rpw == 1) MI_GEMV_S(1, 0); else if (rpw == 2) MI_GEMV_S(2, 0); else MI_GEMV_S(4, 0); }
-#undef MI_GEMV_S
+#define MI_GEMV(R, S, V) hipLaunchKernelGGL((k_gemv_batched<R, S, V>), dim3(ntiles), dim3(64 * V), 0, ctx->stream, meta, x, yslots.p, done)
+#define MI_GEMV_R(S, V) do { if (rpw == 1) MI_GEMV(1, S, V); else if (rpw == 2) MI_GEMV(2, S, V); else MI_GEMV(4, S, V); } while (0)
+    if (waves == 16)     { if (scale) MI_GEMV_R(true, 16); else MI_GEMV_R(false, 16); }
+    else if (waves == 8) { if (scale) MI_GEMV_R(true, 8); else MI_GEMV_R(false, 8); }
+    else                 { if (scale) MI_GEMV_R(true, 4); else MI_GEMV_R(false, 4); }
+#undef MI_GEMV_R
 #undef MI_GEMV
     MI_HIP(hipGetLastError());
   }
@@ -293,6 +324,26 @@ struct DenseBlockOp : Operator {
                        yslots.p, y, done);
     MI_HIP(hipGetLastError());
     ctx->allreduce(y, (size_t)n);
+  }
+  DenseBlockOp *as_dense() override { return this; }
+  // One launch of the folded PCG pair (kernels.hpp k_gemv_pcg); PHASE 1 on the ΠS operator, 0 on S.
+  void gemv_pcg(int phase, const PcgFold &f) {
+    if (!ntiles) return;
+#define MI_PCG3(R, C, V) do { if (phase) hipLaunchKernelGGL((k_gemv_pcg<R, 1, C, V>), dim3(ntiles), dim3(64 * V), 0, ctx->stream, meta, f); \
+                              else hipLaunchKernelGGL((k_gemv_pcg<R, 0, C, V>), dim3(ntiles), dim3(64 * V), 0, ctx->stream, meta, f); } while (0)
+#define MI_PCG2(R, V) do { const int c = (max_nd + 64 * V - 1) / (64 * V); \
+                           if (c <= 2) MI_PCG3(R, 2, V); else if (c == 3) MI_PCG3(R, 3, V); else if (c == 4) MI_PCG3(R, 4, V); \
+                           else if (c == 5) MI_PCG3(R, 5, V); else if (c == 6) MI_PCG3(R, 6, V); else MI_PCG3(R, 8, V); } while (0)
+#define MI_PCG(R) do { if (waves == 16) MI_PCG2(R, 16); else if (waves == 8) MI_PCG2(R, 8); else MI_PCG2(R, 4); } while (0)
+    if (rpw == 1) MI_PCG(1); else if (rpw == 2) MI_PCG(2); else MI_PCG(4);
+#undef MI_PCG
+#undef MI_PCG2
+#undef MI_PCG3
+    MI_HIP(hipGetLastError());
+  }
+  bool same_maps(const DenseBlockOp &o) const {
+    return n == o.n && rpw == o.rpw && waves == o.waves && ntiles == o.ntiles && maps.slot_width == o.maps.slot_width &&
+           maps.nd == o.maps.nd && maps.gidx_h == o.maps.gidx_h;
   }
   AsmView apply_view(const double *x, double *y, const int *done) override {
     if (ctx->comm) return Operator::apply_view(x, y, done);  // the Γ-sum must be materialised for the all-reduce

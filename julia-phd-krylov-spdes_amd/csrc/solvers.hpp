@@ -145,10 +145,36 @@ struct Krylov {
   int n, g;
   hipStream_t s;
   bool fused;  // single-workgroup loop kernels (small Γ systems)
+  bool fold;   // pcg with both operators dense on the same maps: vector work folded into the two GEMVs
+  DenseBlockOp *Ad = nullptr, *Md = nullptr;
 
   Krylov(mi_ctx_s *c, Operator *A_, Operator *M_, int nvec_)
       : ctx(c), A(A_), M(M_), ws(workspace(c, A_->n)), nvec(nvec_), n((int)A_->n), g(ws.g), s(c->stream),
-        fused(A_->n <= FUSED_MAX_N && !env_int("MI355_NO_FUSED", 0)) {}
+        fused(A_->n <= FUSED_MAX_N && !env_int("MI355_NO_FUSED", 0)), fold(false) {
+    if (fused && M && nvec == 0 && !c->comm && !env_int("MI355_NO_FOLD", 0)) {
+      Ad = A->as_dense(); Md = M->as_dense();
+      fold = Ad && Md && !Ad->scale && Md->scale && Ad->same_maps(*Md) && Ad->ntiles > 0 && Ad->max_nd <= GEMV_PANEL && Ad->maps.slot_width <= 4 &&
+             (Ad->max_nd + 64 * Ad->waves - 1) / (64 * Ad->waves) <= 8;
+    }
+  }
+  PcgFold fold_args(int phase) const {
+    PcgFold f{};
+    const size_t nl = (size_t)Ad->maps.nloc;
+    f.st = ws.st; f.W = Ad->maps.slot_width; f.res_norm = ws.res_norm.p; f.x = ws.x; f.r_gamma = ws.r;
+    f.r_cur = Ad->fold_vec.p; f.r_nxt = f.r_cur + nl; f.p_cur = f.r_nxt + nl; f.p_nxt = f.p_cur + nl;
+    f.tgt = Ad->maps.tgt.p; f.peer = Ad->maps.peer.p; f.jrank = Ad->maps.jrank.p;
+    f.n_in = Ad->ntiles;
+    if (phase) {  // ΠS launch: reads S contributions + partial p'Ap, writes ΠS contributions + partial r'r, r'z
+      f.con_in = Ad->fold_con.p; f.con_out = Md->fold_con.p;
+      f.part_in0 = Ad->fold_part0.p; f.part_in1 = nullptr;
+      f.part_out0 = Md->fold_part0.p; f.part_out1 = Md->fold_part1.p;
+    } else {      // S launch: reads ΠS contributions + partial r'r, r'z, writes S contributions + partial p'Ap
+      f.con_in = Md->fold_con.p; f.con_out = Ad->fold_con.p;
+      f.part_in0 = Md->fold_part0.p; f.part_in1 = Md->fold_part1.p;
+      f.part_out0 = Ad->fold_part0.p; f.part_out1 = nullptr;
+    }
+    return f;
+  }
 
   const int *done() const { return &ws.st->done; }
 
@@ -177,6 +203,12 @@ struct Krylov {
     const int *dn = done();
     const int pre = M != nullptr;
     const double *Wp = nvec > 0 ? ws.W.p : nullptr, *mup = nvec > 0 ? ws.mu.p : nullptr;
+    if (fold) {
+      // 2 launches per iteration: (alpha, x, r, z, r'z, r'r) in the ΠS GEMV; (stop rule, beta, p, Ap, p'Ap) in the S GEMV
+      Md->gemv_pcg(1, fold_args(1));
+      Ad->gemv_pcg(0, fold_args(0));
+      return;
+    }
     if (fused) {
       // small Γ systems: 4 launches per iteration (GEMV, fused, GEMV, fused)
       const AsmView vAp = A->apply_view(ws.p, ws.Ap, dn);             // mul!(Ap, A, p), Γ-sum deferred
@@ -215,9 +247,17 @@ struct Krylov {
   // eps / maxit / res_cap are read from the state block (uploaded by solve()), so this is graph-replayable.
   void setup_tail() {
     const int pre = M != nullptr;
+    if (fold) {
+      const AsmView vAp = A->apply_view(ws.x, ws.Ap, nullptr);
+#define MI_CALL(E) hipLaunchKernelGGL((k_fused_residual<E, true>), dim3(1), dim3(NTF), 0, s, n, ws.st, vAp, ws.b, ws.r)
+      MI_EPT_DISPATCH(MI_CALL);
+#undef MI_CALL
+      MI_HIP(hipGetLastError());
+      return;
+    }
     if (fused && nvec == 0) {
       const AsmView vAp = A->apply_view(ws.x, ws.Ap, nullptr);
-#define MI_CALL(E) hipLaunchKernelGGL((k_fused_residual<E>), dim3(1), dim3(NTF), 0, s, n, ws.st, vAp, ws.b, ws.r)
+#define MI_CALL(E) hipLaunchKernelGGL((k_fused_residual<E, false>), dim3(1), dim3(NTF), 0, s, n, ws.st, vAp, ws.b, ws.r)
       MI_EPT_DISPATCH(MI_CALL);
 #undef MI_CALL
       const AsmView vz = pre ? M->apply_view(ws.r, ws.z, nullptr) : AsmView{ws.r, 0};
@@ -268,7 +308,8 @@ struct Krylov {
   }
 
   void fetch_flags(int slot) {
-    MI_HIP(hipMemcpyAsync(&ws.flags[slot].it, &ws.st->it, sizeof(long long), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipMemcpyAsync(&ws.flags[slot].it, fold ? &ws.st->it_nxt : &ws.st->it, sizeof(long long),
+                          hipMemcpyDeviceToHost, s));
     MI_HIP(hipMemcpyAsync(&ws.flags[slot].done, &ws.st->done, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     MI_HIP(hipEventRecord(ws.ev[slot], s));
   }
@@ -344,7 +385,7 @@ struct Krylov {
         enqueue_results(0);
         MI_HIP(hipStreamSynchronize(s));
       }
-      predicted = (int)std::max<long long>(1, ws.flags[0].it - 1);
+      predicted = (int)std::max<long long>(1, ws.flags[0].it - (fold ? 0 : 1));  // the folded pair checks the stop rule one launch later
     } else {
       setup_tail();
       for (int64_t l = 0; l < maxit + 2; ++l) {

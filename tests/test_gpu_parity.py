@@ -291,3 +291,44 @@ def test_rccl_single_rank_communicator(pkg, ctx, orc, micro):
     S, M = gpu_ops(pkg, c2, P)
     So, Mo = orc_ops(orc, P)
     assert_history(api.pcg(S, P.b_schur, np.zeros(P.sub.n_Γ), M), orc.pcg(So, P.b_schur, np.zeros(P.sub.n_Γ), Mo))
+
+
+# ------------------------------------------------------------------ folded PCG (2 launches / iteration) vs the other loop forms
+def test_folded_unfolded_and_eager_loops_agree(pkg, ctx, orc, fem):
+    """pcg(S, b, x, ΠSnn) has three device forms: folded into the GEMVs (default), 4 launches with fused
+    single-workgroup kernels (what a communicator or deflation selects), and multi-workgroup kernels.
+    All must reproduce the oracle; here on strips (multiplicity 2 everywhere, slot width 2), on a 4x2
+    partition (cross points, width 4) and with a non-zero initial guess."""
+    import os
+    import subprocess
+    import sys
+    api = pkg.api
+    for (N, px, py, seed) in ((60, 3, 1, 3), (90, 4, 2, 5)):
+        mesh = fem.get_mesh(N)
+        P = fem.build_schur_problem(N, px, py, lognormal_coeff(fem, mesh.points, seed), f_m1, u0734)
+        S, M = gpu_ops(pkg, ctx, P)
+        So, Mo = orc_ops(orc, P)
+        n, b = P.sub.n_Γ, P.b_schur
+        for x0 in (np.zeros(n), np.random.default_rng(seed).standard_normal(n)):
+            want = orc.pcg(So, b, x0, Mo)
+            assert_history(api.pcg(S, b, x0, M), want)
+            assert_history(api.pcg(S, b, x0, M, maxit=4), orc.pcg(So, b, x0, Mo, maxit=4))
+    # the same solve with the fold / the fused kernels switched off (environment is read per solve)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests');"
+            "import __graft_entry__ as g; from conftest import *; pkg = g.load_package(); fem, api = pkg.fem, pkg.api;"
+            "P = fem.build_schur_problem(40, 2, 2, one, f_m1, u0734); ctx = api.Context(0);"
+            "S = api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt);"
+            "M = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt);"
+            "x, it, res = api.pcg(S, P.b_schur, np.zeros(P.sub.n_Γ), M); print(it, ' '.join(repr(float(v)) for v in res))")
+    from conftest import ROOT
+    outs = []
+    for env in ({}, {"MI355_NO_FOLD": "1"}, {"MI355_NO_FOLD": "1", "MI355_NO_FUSED": "1"}):
+        r = subprocess.run([sys.executable, "-c", code % (ROOT, ROOT)], env={**os.environ, **env},
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        tok = r.stdout.split()
+        outs.append((int(tok[0]), np.array([float(t) for t in tok[1:]])))
+    G = np.load(f"{GOLDEN}/micro.npz")
+    for it, res in outs:
+        assert it == int(G["pcg_it"])
+        assert np.allclose(res, G["pcg_res_norm"], rtol=RES_RTOL, atol=RES_FLOOR * res[0])

@@ -137,6 +137,7 @@ struct mi_ctx_s {
   int chunk = 8;
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1;
+  bool no_graph = false;  // set when a captured collective could not be instantiated: eager launches from then on
   // scratch for BLAS-1 entry points and reductions
   mi::DevBuf<double> scratch_a, scratch_b, partials, scalar;
   // solver workspaces keyed by problem size; graphs keyed inside

@@ -203,6 +203,12 @@ int mi_ctx_comm_init(mi_ctx_t ctx, const void *id, int rank, int n_ranks) {
     MI_NCCL(Rccl::get().CommInitRank(&ctx->comm, n_ranks, uid, rank));
     ctx->rank = rank; ctx->n_ranks = n_ranks;
     for (auto &kv : ctx->workspaces) kv.second->drop_graphs();
+    // Warm-up collective outside any stream capture: RCCL sets up its channels lazily on first use,
+    // which must not happen while an iteration graph is being captured.
+    ctx->scalar.ensure(1);
+    MI_HIP(hipMemsetAsync(ctx->scalar.p, 0, sizeof(double), ctx->stream));
+    ctx->allreduce(ctx->scalar.p, 1);
+    MI_HIP(hipStreamSynchronize(ctx->stream));
     return MI_OK;
   });
 }

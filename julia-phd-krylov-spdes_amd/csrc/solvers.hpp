@@ -352,7 +352,7 @@ struct Krylov {
     }
 
     // ---- set-up tail + loop
-    const bool use_graph = ctx->chunk > 0 && A->graph_safe() && (!M || M->graph_safe());
+    bool use_graph = ctx->chunk > 0 && A->graph_safe() && (!M || M->graph_safe()) && !ctx->no_graph;
     const int64_t ncap = std::min<int64_t>(res_cap, cap_dev);
     const bool spec_res = res_host && ncap > 0 && ncap <= RES_STAGE;
     auto enqueue_results = [&](int slot) {
@@ -365,7 +365,18 @@ struct Krylov {
       int &predicted = ws.predicted[pk];
       const int64_t first = std::max<int64_t>(1, std::min<int64_t>(predicted > 0 ? predicted : ctx->chunk,
                                                                   std::min<int64_t>(maxit, 1024)));
-      MI_HIP(hipGraphLaunch(graph(-(int)first), s));
+      hipGraphExec_t g0 = nullptr;
+      try {
+        g0 = graph(-(int)first);
+      } catch (const Error &) {
+        // A collective that cannot be captured (communicator attached): run this context eagerly from now on.
+        // Every rank takes the same path because capture fails or succeeds identically on all of them.
+        if (!ctx->comm) throw;
+        ctx->no_graph = true;
+        use_graph = false;
+      }
+      if (use_graph) {
+      MI_HIP(hipGraphLaunch(g0, s));
       enqueue_results(0);
       MI_HIP(hipStreamSynchronize(s));
       if (!ws.flags[0].done) {
@@ -386,7 +397,9 @@ struct Krylov {
         MI_HIP(hipStreamSynchronize(s));
       }
       predicted = (int)std::max<long long>(1, ws.flags[0].it - (fold ? 0 : 1));  // the folded pair checks the stop rule one launch later
-    } else {
+      }
+    }
+    if (!use_graph) {
       setup_tail();
       for (int64_t l = 0; l < maxit + 2; ++l) {
         fetch_flags(0);

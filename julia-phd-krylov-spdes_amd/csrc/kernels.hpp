@@ -112,19 +112,22 @@ __global__ __launch_bounds__(NT) void k_diag_apply(int n, const double *__restri
 // XCD's L2 caches one slice of x instead of all of it.
 constexpr int SPMV_TILE = 2048;
 
-template <int MODE>  // 0: y = A x      1: y = yin - A x
+template <int MODE, bool DOT>  // MODE 0: y = A x, 1: y = yin - A x;  DOT: also part[b] = Σ_{rows of block b} w[r]*y[r]
 __global__ __launch_bounds__(NT) void k_spmv_csr(int nblocks, const int *__restrict__ rb,
                                                  const int *__restrict__ rowptr, const int *__restrict__ col,
                                                  const double *__restrict__ val, const double *__restrict__ x,
-                                                 const double *yin, double *y, const int *done) {
+                                                 const double *yin, double *y, const double *__restrict__ w,
+                                                 double *__restrict__ part, const int *done) {
   if (done && *done) return;
   __shared__ double prod[SPMV_TILE];
+  __shared__ double sm[NT / 64 + 1];
   const int per = (nblocks + 7) >> 3;
   const int b = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (b >= nblocks) return;
   const int r0 = rb[b], r1 = rb[b + 1];
   const int k0 = rowptr[r0], k1 = rowptr[r1];
   const int nnz = k1 - k0;
+  double wy = 0.0;
   if (nnz <= SPMV_TILE) {
     for (int k = threadIdx.x; k < nnz; k += NT) prod[k] = val[k0 + k] * x[col[k0 + k]];
     __syncthreads();
@@ -132,7 +135,9 @@ __global__ __launch_bounds__(NT) void k_spmv_csr(int nblocks, const int *__restr
       const int a = rowptr[r] - k0, e = rowptr[r + 1] - k0;
       double s = 0.0;
       for (int k = a; k < e; ++k) s += prod[k];
-      y[r] = MODE ? yin[r] - s : s;
+      const double yr = MODE ? yin[r] - s : s;
+      y[r] = yr;
+      if (DOT) wy += w[r] * yr;
     }
   } else {
     // a single row longer than the tile (never the case for P1-FEM blocks): tile by tile,
@@ -146,7 +151,15 @@ __global__ __launch_bounds__(NT) void k_spmv_csr(int nblocks, const int *__restr
         for (int k = 0; k < m; ++k) s += prod[k];
       __syncthreads();
     }
-    if (threadIdx.x == 0) y[r0] = MODE ? yin[r0] - s : s;
+    if (threadIdx.x == 0) {
+      const double yr = MODE ? yin[r0] - s : s;
+      y[r0] = yr;
+      if (DOT) wy = w[r0] * yr;
+    }
+  }
+  if (DOT) {
+    wy = block_sum(wy, sm);
+    if (threadIdx.x == 0) part[b] = wy;
   }
 }
 
@@ -575,27 +588,37 @@ __global__ __launch_bounds__(NT) void k_init_state(SolverState *st, const double
   }
 }
 // Loop step 1:  d = p'Ap (from partials); alpha = num/d; x += alpha p; r -= alpha Ap; partial r'r.
-// num = r'z (pcg, cg.jl:95) or r'r (cg, cg.jl:38).
+// num = r'z (pcg, cg.jl:95) or r'r (cg, cg.jl:38). With a diagonal preconditioner (diag 1: identity,
+// 2: Jacobi) `z .= M \ r` and the partial r'z (cg.jl:100-101) are produced in the same pass.
 __global__ __launch_bounds__(NT) void k_update_xr(int n, SolverState *st, const double *part_pAp, int g_in,
                                                   const double *__restrict__ p, const double *__restrict__ Ap,
                                                   double *__restrict__ x, double *__restrict__ r,
-                                                  double *__restrict__ part_rr, int precond) {
+                                                  double *__restrict__ part_rr, int precond, int diag,
+                                                  const double *__restrict__ dinv, double *__restrict__ z,
+                                                  double *__restrict__ part_rz) {
   if (st->done) return;
   __shared__ double sm[NT / 64 + 1];
   const double d = sum_partials(part_pAp, g_in, sm);
   const double num = precond ? st->rTz : st->rTr;
   const double alpha = num / d;
-  double srr = 0.0;
+  double srr = 0.0, srz = 0.0;
   for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
     const double pi = p[i];
     x[i] = x[i] + alpha * pi;          // axpy!(alpha, p, x)
     const double ri = r[i] + (-alpha) * Ap[i];  // axpy!(-alpha, Ap, r)
     r[i] = ri;
     srr += ri * ri;
+    if (diag) {
+      const double zi = diag == 2 ? dinv[i] * ri : ri;
+      z[i] = zi;
+      srz += ri * zi;
+    }
   }
   srr = block_sum(srr, sm);
+  if (diag) srz = block_sum(srz, sm);
   if (threadIdx.x == 0) {
     part_rr[blockIdx.x] = srr;
+    if (diag) part_rz[blockIdx.x] = srz;
     if (blockIdx.x == 0) {
       st->d = d; st->alpha = alpha;
       st->rTr_prev = st->rTr; st->rTz_prev = st->rTz;

@@ -38,6 +38,12 @@ struct Operator {
     apply(x, y, done);
     return AsmView{y, 0};
   }
+  // Optional fusions the solver asks for: y = Op(x) together with per-workgroup partials of w'y; and, for a
+  // preconditioner, "I am diagonal" (1: identity, 2: Jacobi with `*dinv`) so that z = M \ r is folded into the r-update.
+  virtual bool apply_dot(const double *x, double *y, const double *w, const double **part, int *count, const int *done) {
+    return false;
+  }
+  virtual int diag_kind(const double **dinv) const { return 0; }
   virtual DenseBlockOp *as_dense() { return nullptr; }
   virtual bool graph_safe() const { return true; }  // false: apply synchronises with the host
   virtual void bytes(int64_t *apply_b, int64_t *dominant_b) const = 0;
@@ -116,16 +122,15 @@ struct CsrDev {
     if (rp.empty()) rp.push_back(0);
     rowptr.upload(rp, s); col.upload(h.col, s); val.upload(h.val, s); rb.upload(blocks, s);
   }
-  // y = A x (mode 0) or y = yin - A x (mode 1)
-  void launch(int mode, const double *x, const double *yin, double *y, const int *done, hipStream_t s) const {
+  // y = A x (mode 0) or y = yin - A x (mode 1); with `w`: also part[b] = Σ w[r] y[r] over the rows of block b
+  void launch(int mode, const double *x, const double *yin, double *y, const int *done, hipStream_t s,
+              const double *w = nullptr, double *part = nullptr) const {
     if (nblocks == 0) return;
     const int grid = ((nblocks + 7) / 8) * 8;
-    if (mode == 0)
-      hipLaunchKernelGGL(k_spmv_csr<0>, dim3(grid), dim3(NT), 0, s, nblocks, rb.p, rowptr.p, col.p, val.p, x,
-                         (const double *)nullptr, y, done);
-    else
-      hipLaunchKernelGGL(k_spmv_csr<1>, dim3(grid), dim3(NT), 0, s, nblocks, rb.p, rowptr.p, col.p, val.p, x, yin, y,
-                         done);
+#define MI_SPMV(M, D) hipLaunchKernelGGL((k_spmv_csr<M, D>), dim3(grid), dim3(NT), 0, s, nblocks, rb.p, rowptr.p, col.p, val.p, x, yin, y, w, part, done)
+    if (mode == 0) { if (w) MI_SPMV(0, true); else MI_SPMV(0, false); }
+    else           { if (w) MI_SPMV(1, true); else MI_SPMV(1, false); }
+#undef MI_SPMV
     MI_HIP(hipGetLastError());
   }
   // 12 nnz + 4 (rows+1) + 8 cols (x once) + 8 rows (y)
@@ -139,11 +144,19 @@ struct CsrOp : Operator {
   CsrOp(mi_ctx_s *c, const HostCsr &h) : Operator(c, h.n_rows) {
     if (h.n_rows != h.n_cols) raise(MI_ERR_BAD_ARG, "mi_csr_create: solver operators must be square");
     A.upload(h, c->stream);
+    dot_part.alloc((size_t)A.nblocks + 1);  // not inside apply_dot: that may run under stream capture
+    sink.alloc((size_t)n + 1);
   }
+  DevBuf<double> dot_part;
   void apply(const double *x, double *y, const int *done) override { A.launch(0, x, nullptr, y, done, ctx->stream); }
+  bool apply_dot(const double *x, double *y, const double *w, const double **part, int *count, const int *done) override {
+    if (A.nblocks == 0) return false;
+    A.launch(0, x, nullptr, y, done, ctx->stream, w, dot_part.p);
+    *part = dot_part.p; *count = A.nblocks;
+    return true;
+  }
   void bytes(int64_t *a, int64_t *d) const override { *a = *d = A.bytes(); }
   void apply_dominant(const double *x) override {
-    sink.ensure((size_t)n);
     A.launch(0, x, nullptr, sink.p, nullptr, ctx->stream);
   }
 };
@@ -160,6 +173,7 @@ struct DiagOp : Operator {
                        identity ? (const double *)nullptr : dinv.p, x, y, done);
     MI_HIP(hipGetLastError());
   }
+  int diag_kind(const double **d) const override { *d = identity ? nullptr : dinv.p; return identity ? 1 : 2; }
   void bytes(int64_t *a, int64_t *d) const override { *a = *d = (identity ? 16 : 24) * n; }
   void apply_dominant(const double *) override {}
 };

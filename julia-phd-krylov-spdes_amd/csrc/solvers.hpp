@@ -227,14 +227,24 @@ struct Krylov {
       MI_HIP(hipGetLastError());
       return;
     }
-    A->apply(ws.p, ws.Ap, dn);                                        // mul!(Ap, A, p)
-    dot_partial(ws.p, ws.Ap, ws.part_pAp, dn);                        // d = dot(p, Ap)
-    hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(NT), 0, s, n, ws.st, ws.part_pAp, g, ws.p, ws.Ap, ws.x, ws.r,
-                       ws.part_rr, pre);                              // alpha; x += alpha p; r -= alpha Ap; r'r
+    // large systems (full A): SpMV with the p'Ap partials in its epilogue; r-update with a diagonal M folded in
+    const double *part = ws.part_pAp;
+    int npart = g;
+    if (!A->apply_dot(ws.p, ws.Ap, ws.p, &part, &npart, dn)) {       // mul!(Ap, A, p); d = dot(p, Ap)
+      A->apply(ws.p, ws.Ap, dn);
+      dot_partial(ws.p, ws.Ap, ws.part_pAp, dn);
+      part = ws.part_pAp; npart = g;
+    }
+    const double *dinv = nullptr;
+    const int diag = pre ? M->diag_kind(&dinv) : 0;
+    hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(NT), 0, s, n, ws.st, part, npart, ws.p, ws.Ap, ws.x, ws.r,
+                       ws.part_rr, pre, diag, dinv, ws.z, ws.part_rz);  // alpha; x += alpha p; r -= alpha Ap; r'r [; z; r'z]
     const double *zz = ws.r;
     if (pre) {
-      M->apply(ws.r, ws.z, dn);                                       // z .= M \ r
-      dot_partial(ws.r, ws.z, ws.part_rz, dn);                        // rTz = dot(r, z)
+      if (!diag) {
+        M->apply(ws.r, ws.z, dn);                                     // z .= M \ r
+        dot_partial(ws.r, ws.z, ws.part_rz, dn);                      // rTz = dot(r, z)
+      }
       zz = ws.z;
     }
     if (nvec > 0) project(ws.AW.p, zz, dn);                           // mu .= WtAW \ (WtA * z)

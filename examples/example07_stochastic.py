@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Example07_PcgSchurStochasticEllipticPde.jl (lines 56-285) on the MI355X drop-in — BASELINE config 5.
+
+For every realization ξ_t of the lognormal coefficient: rebuild the local blocks, b_schur, the assembled
+S_d and NN_t on the host (as the reference does), then on the GPU
+    pcg(S, b_schur, 0, ΠSnn_0)        (Example07:273)   preconditioner of the ξ = 0 operator, built once
+    pcg(S, b_schur, 0, ΠSnn_t)        (Example07:277)   preconditioner of this realization
+    defpcg(S, b_schur, 0, W_0, ΠSnn_0)                  deflation with the nev least-dominant eigenvectors of
+                                                        S_0 (the `defpcg` variant that Example07 keeps in its
+                                                        trailing comment block, with W fixed instead of recycled)
+and record the iteration counts. Realizations are independent: under torch.distributed.run each rank takes
+realizations rank, rank+world, ... on its own GPU (replicas only, no collective in the solve).
+
+    python examples/example07_stochastic.py [--N 200 --px 4 --py 2 --nreals 20]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--N", type=int, default=200)
+    ap.add_argument("--px", type=int, default=4)
+    ap.add_argument("--py", type=int, default=2)
+    ap.add_argument("--nreals", type=int, default=20)   # Example07:29 nreals = 1000
+    ap.add_argument("--seed", type=int, default=481456)
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    pkg = graft.load_package()
+    fem, api = pkg.fem, pkg.api
+    f = lambda x, y: -1.0 + 0 * x
+    uexact = lambda x, y: 0.734 + 0 * x
+    mesh = fem.get_mesh(args.N)
+    kl = fem.synthetic_kl(mesh.points)
+    rng = np.random.default_rng(args.seed)
+    gs = [fem.draw(kl, rng)[1] for _ in range(args.nreals)]          # Example07:140-144: all draws up front
+
+    ctx = api.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    P0 = fem.build_schur_problem(args.N, args.px, args.py, np.exp(0 * gs[0]), f, uexact)   # ξ = 0 operator (:88-137)
+    sub = P0.sub
+    n_Γ, ndom = sub.n_Γ, sub.ndom
+    ΠSnn_0 = api.NeumannNeumannSchurPreconditioner(ctx, P0.ΠSd, sub.gather_idx, sub.node_Γ_cnt)      # :152-154
+    S_0 = api.LocalSchurs(ctx, P0.Sd, sub.gather_idx, sub.node_Γ_cnt)
+    S0d = np.column_stack([S_0 * e for e in np.eye(n_Γ)])
+    W_0 = np.asfortranarray(np.linalg.eigh((S0d + S0d.T) / 2)[1][:, :ndom + 10])
+
+    iters_0, iters_t, iters_def = [], [], []
+    for ireal in range(rank, args.nreals, world):
+        P = fem.build_schur_problem(args.N, args.px, args.py, np.exp(gs[ireal]), f, uexact)          # :162-199
+        S = api.LocalSchurs(ctx, P.Sd, sub.gather_idx, sub.node_Γ_cnt)
+        ΠSnn_t = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, sub.gather_idx, sub.node_Γ_cnt)
+        x0 = np.zeros(n_Γ)
+        iters_0.append(api.pcg(S, P.b_schur, x0, ΠSnn_0)[1])                                          # :273
+        iters_t.append(api.pcg(S, P.b_schur, x0, ΠSnn_t)[1])                                          # :277
+        iters_def.append(api.defpcg(S, P.b_schur, x0, W_0, ΠSnn_0)[1])
+        print(f"[rank {rank}] realization {ireal}: pcg(NN_0) it={iters_0[-1]}  pcg(NN_t) it={iters_t[-1]}  "
+              f"defpcg(W_0, NN_0) it={iters_def[-1]}", flush=True)
+    if args.out:                                                                                       # :281-285 npz of iteration counts
+        np.savez(args.out.format(rank=rank), iters_0=iters_0, iters_t=iters_t, iters_def=iters_def)
+    print(f"[rank {rank}] mean its: NN_0 {np.mean(iters_0):.1f}  NN_t {np.mean(iters_t):.1f}  def {np.mean(iters_def):.1f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmi355schur.so")
+LIB_PATH = os.environ.get("MI355SCHUR_LIB") or os.path.join(_PKG, "libmi355schur.so")   # override: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
 
 MI_OK = 0

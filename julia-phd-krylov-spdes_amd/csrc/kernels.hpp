@@ -192,23 +192,40 @@ struct DenseMeta {
   const int *out_pos;     // [nloc] slot g*W + j of every local row
 };
 constexpr int GEMV_PANEL = 2048;  // doubles of x_d staged per pass (16 KiB LDS)
+#ifndef MI355_GEMV_GU
+#define MI355_GEMV_GU 4        // 16-byte loads per lane and row in one group
+#endif
+#ifndef MI355_GEMV_NT
+#define MI355_GEMV_NT 0        // 1: non-temporal matrix loads
+#endif
+constexpr int GU = MI355_GEMV_GU;
+__device__ __forceinline__ double2 gemv_ld(const double *p) {
+#if MI355_GEMV_NT
+  double2 v;
+  v.x = __builtin_nontemporal_load(p);
+  v.y = __builtin_nontemporal_load(p + 1);
+  return v;
+#else
+  return *reinterpret_cast<const double2 *>(p);
+#endif
+}
 
 template <int RPW>
-__device__ __forceinline__ void gemv_load_group(double2 (&mv)[RPW][4], const double *const (&rowp)[RPW], int col0,
+__device__ __forceinline__ void gemv_load_group(double2 (&mv)[RPW][GU], const double *const (&rowp)[RPW], int col0,
                                                 int cb, int pw, int lane) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < GU; ++u) {
     const int c = cb + u * 128 + lane * 2;
 #pragma unroll
     for (int k = 0; k < RPW; ++k)
-      mv[k][u] = (c < pw) ? *reinterpret_cast<const double2 *>(rowp[k] + col0 + c) : make_double2(0.0, 0.0);
+      mv[k][u] = (c < pw) ? gemv_ld(rowp[k] + col0 + c) : make_double2(0.0, 0.0);
   }
 }
 template <int RPW>
-__device__ __forceinline__ void gemv_fma_group(double (&acc)[RPW], const double2 (&mv)[RPW][4], const double *xs, int cb,
+__device__ __forceinline__ void gemv_fma_group(double (&acc)[RPW], const double2 (&mv)[RPW][GU], const double *xs, int cb,
                                                int pw, int lane) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < GU; ++u) {
     const int c = cb + u * 128 + lane * 2;
     const double2 xv = (c < pw) ? *reinterpret_cast<const double2 *>(&xs[c]) : make_double2(0.0, 0.0);
 #pragma unroll
@@ -225,7 +242,7 @@ template <int RPW>
 struct GemvRows {
   const double *rowp[RPW];
   double acc[RPW];
-  double2 buf[RPW][4];
+  double2 buf[RPW][GU];
   int lane, ld;
   __device__ __forceinline__ void begin(const DenseMeta &m, const GemvTile &t) {
     lane = threadIdx.x & 63;
@@ -243,7 +260,7 @@ struct GemvRows {
   // xs holds columns [c0, c0 + pw) of the operand; for c0 > 0 the first group is loaded here
   __device__ __forceinline__ void panel(const double *xs, int c0, int pw) {
     if (c0) gemv_load_group<RPW>(buf, rowp, c0, 0, pw, lane);
-    for (int cb = 0; cb < pw; cb += 512) {
+    for (int cb = 0; cb < pw; cb += 128 * GU) {
       if (cb) gemv_load_group<RPW>(buf, rowp, c0, cb, pw, lane);
       gemv_fma_group<RPW>(acc, buf, xs, cb, pw, lane);
     }

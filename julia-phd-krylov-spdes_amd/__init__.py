@@ -4,12 +4,15 @@ The directory name is not a Python identifier; load it with `__graft_entry__.loa
 which registers it as `krylov_spdes_amd`:
 
     fem  - host-side set-up mirror (mesh, partition, blocks, S_d, pinv) — feeds the path
+    io   - the reference's npz mesh / partition / iteration-count files
     api  - reference-named operators / preconditioner / solvers over the C ABI (HIP only)
     _lib - ctypes binding of libmi355schur.so (include/mi355schur.h)
 """
 from . import fem  # noqa: F401  (pure numpy/scipy; importable without the HIP library)
 
-__all__ = ["fem", "api", "_lib"]
+from . import io  # noqa: F401,E402
+
+__all__ = ["fem", "io", "api", "_lib"]
 
 
 def __getattr__(name):

@@ -193,23 +193,12 @@ struct DenseMeta {
 };
 constexpr int GEMV_PANEL = 2048;  // doubles of x_d staged per pass (16 KiB LDS)
 #ifndef MI355_GEMV_GU
-#define MI355_GEMV_GU 4        // 16-byte loads per lane and row in one group
-#endif
-#ifndef MI355_GEMV_NT
-#define MI355_GEMV_NT 0        // 1: non-temporal matrix loads
+#define MI355_GEMV_GU 4        // 16-byte loads per lane and row in one group (2 and 8 measured slower, profiles/)
 #endif
 constexpr int GU = MI355_GEMV_GU;
-__device__ __forceinline__ double2 gemv_ld(const double *p) {
-#if MI355_GEMV_NT
-  double2 v;
-  v.x = __builtin_nontemporal_load(p);
-  v.y = __builtin_nontemporal_load(p + 1);
-  return v;
-#else
-  return *reinterpret_cast<const double2 *>(p);
-#endif
-}
-
+// Default-policy loads on purpose: the 136 MB working set of a PCG iteration is re-read from the Infinity
+// Cache every iteration; non-temporal loads made the stand-alone GEMV 3 % faster and the solve 4 % slower.
+__device__ __forceinline__ double2 gemv_ld(const double *p) { return *reinterpret_cast<const double2 *>(p); }
 template <int RPW>
 __device__ __forceinline__ void gemv_load_group(double2 (&mv)[RPW][GU], const double *const (&rowp)[RPW], int col0,
                                                 int cb, int pw, int lane) {

@@ -184,7 +184,7 @@ struct LocalMaps {
   int nloc = 0;  // Σ n_Γd over local subdomains
   std::vector<int> nd, loc_off, gidx_h;
   DevBuf<int> gidx, aptr, apos, out_pos;
-  DevBuf<int> jrank, peer, tgt, gpeer;  // local-order bookkeeping of the folded PCG launches (kernels.hpp PcgFold)
+  DevBuf<int> jrank, peer, tgt;  // local-order bookkeeping of the folded PCG launches (kernels.hpp PcgFold)
   int slot_width = 1;  // W: contribution slots per Γ node (max multiplicity over this rank's subdomains)
   void build(mi_ctx_s *c, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d, const int64_t *const *gather_idx,
              int base, int64_t d0, int64_t d1) {
@@ -229,16 +229,14 @@ struct LocalMaps {
       for (int k = cntv[i]; k < cntv[i + 1]; ++k) op[pos[k]] = (int)(i * slot_width + (k - cntv[i]));
     out_pos.upload(op, c->stream);
     // folded PCG: for local position `loc` of Γ node g with contributors loc_0 < loc_1 < ... (ascending subdomain):
-    //   jrank[loc] = my rank among them; peer[loc*W+k] = loc_k; tgt[loc*W+k] = loc_k*W + jrank[loc];
-    //   gpeer[g*W+k] = loc_k
+    //   jrank[loc] = my rank among them; peer[loc*W+k] = loc_k; tgt[loc*W+k] = loc_k*W + jrank[loc]
     const int W = slot_width;
-    std::vector<int> jr(nloc), pe((size_t)nloc * W + 4, -1), tg((size_t)nloc * W + 4, -1), gp((size_t)n_gamma * W + 4, -1);
+    std::vector<int> jr(nloc), pe((size_t)nloc * W + 4, -1), tg((size_t)nloc * W + 4, -1);
     for (int64_t i = 0; i < n_gamma; ++i) {
       const int m = cntv[i + 1] - cntv[i];
       for (int a = 0; a < m; ++a) {
         const int la = pos[cntv[i] + a];
         jr[la] = a;
-        gp[(size_t)i * W + a] = la;
         for (int k = 0; k < m; ++k) {
           const int lk = pos[cntv[i] + k];
           pe[(size_t)la * W + k] = lk;
@@ -246,7 +244,7 @@ struct LocalMaps {
         }
       }
     }
-    jrank.upload(jr, c->stream); peer.upload(pe, c->stream); tgt.upload(tg, c->stream); gpeer.upload(gp, c->stream);
+    jrank.upload(jr, c->stream); peer.upload(pe, c->stream); tgt.upload(tg, c->stream);
   }
   void assemble(mi_ctx_s *c, int64_t n_gamma, const double *yloc, double *y, const int *done) const {
     hipLaunchKernelGGL(k_assemble, dim3(vec_grid(n_gamma)), dim3(NT), 0, c->stream, (int)n_gamma, aptr.p, apos.p, yloc,

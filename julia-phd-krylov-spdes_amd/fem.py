@@ -651,7 +651,8 @@ class SchurProblem:
 
 
 def build_schur_problem(N: int, px: int, py: int, coeff: Coeff, f, uexact,
-                        assemble: bool = True, precond: bool = True, dom_slice=None) -> SchurProblem:
+                        assemble: bool = True, precond: bool = True, dom_slice=None,
+                        mesh: Optional[Mesh] = None, partition=None) -> SchurProblem:
     """Example03:45-150 set-up flow on the synthetic mesh (mesh → partition → maps →
     local blocks → b_schur → assembled S_d → Neumann-Neumann pseudo-inverses).
 
@@ -659,10 +660,12 @@ def build_schur_problem(N: int, px: int, py: int, coeff: Coeff, f, uexact,
     only subdomains lo..hi-1; the other entries of `solvers`, `Sd`, `ΠSd` are None and
     `b_schur` then holds only this rank's share  -Σ_{d in slice} R_d' A_IΓd' A_IId^{-1} b_Id
     (+ b_Γ on the rank that owns subdomain 0), so that the sum over ranks is the full b_schur.
+    `mesh` / `partition=(epart, npart)` replace the structured substitutes, e.g. with files written by the
+    reference's Triangle + METIS pipeline (io.load_mesh / io.load_partition).
     """
-    mesh = get_mesh(N)
+    mesh = get_mesh(N) if mesh is None else mesh
     dinds = get_dirichlet_inds(mesh.points, mesh.point_marker)
-    epart, npart = mesh_partition(mesh, px, py)
+    epart, npart = mesh_partition(mesh, px, py) if partition is None else partition
     sub = set_subdomains(mesh.cells, mesh.cell_neighbors, epart, npart, dinds.dirichlet_g2l)
     A_II, A_IΓ, A_ΓΓ, b_Id, b_Γ = prepare_local_schurs(mesh.cells, mesh.points, epart, sub, coeff, f, uexact)
     lo, hi = (0, sub.ndom) if dom_slice is None else dom_slice

@@ -233,3 +233,51 @@ def test_oracle_reproduces_golden(orc, fem, name, micro, toy):
         assert it == int(G[f"{tag}_it"])
         assert np.array_equal(res, G[f"{tag}_res_norm"])
         assert np.array_equal(x, G[f"{tag}_x"])
+
+
+# ------------------------------------------------------------------ reference on-disk formats
+def test_reference_npz_round_trip(pkg, fem, tmp_path):
+    """save_mesh/load_mesh, save_partition/load_partition in the reference's layout (Fem/Mesh.jl:49-91, 216-247):
+    a problem built from the files equals the one built in memory, including on a mesh whose element order
+    and neighbour table are permuted (nothing below relies on the structured numbering)."""
+    io = pkg.io
+    d = str(tmp_path / "data")
+    mesh = fem.get_mesh(24)
+    epart, npart = fem.mesh_partition(mesh, 2, 2)
+    io.save_mesh(mesh, 576, d)
+    io.save_partition(epart, npart, 576, 4, d)
+    # on disk: cells nel x 3 and 0-based, points nnode x 2, neighbours 1-based with -1 (what set_subdomains expects)
+    c = np.load(io.mesh_paths(d, 576)["cells"])
+    assert c.shape == (mesh.cells.shape[1], 3) and c.min() == 0
+    nb = np.load(io.mesh_paths(d, 576)["cell_neighbors"])
+    assert nb.min() == -1 and nb.max() == mesh.cells.shape[1]
+    m2 = io.load_mesh(576, d)
+    e2, n2 = io.load_partition(576, 4, d)
+    for a, b in ((mesh.cells, m2.cells), (mesh.points, m2.points), (mesh.point_marker, m2.point_marker),
+                 (mesh.cell_neighbors, m2.cell_neighbors), (epart, e2), (npart, n2)):
+        assert np.array_equal(a, b)
+    # TriangleMesh's other convention: neighbour indices one too large (EPDD.jl:106-111 corrects it)
+    shifted = np.where(mesh.cell_neighbors < 0, 0, mesh.cell_neighbors + 2)
+    io._write(io.mesh_paths(d, 576)["cell_neighbors"], shifted.T)
+    assert np.array_equal(io.load_mesh(576, d).cell_neighbors, mesh.cell_neighbors)
+    P1 = fem.build_schur_problem(24, 2, 2, one, f_m1, u0734)
+    P2 = fem.build_schur_problem(24, 2, 2, one, f_m1, u0734, mesh=m2, partition=(e2, n2))
+    assert np.array_equal(P1.b_schur, P2.b_schur) and all(np.array_equal(a, b) for a, b in zip(P1.Sd, P2.Sd))
+    # a shuffled element order (an unstructured mesh as far as the code can tell)
+    perm = np.random.default_rng(0).permutation(mesh.cells.shape[1])
+    inv = np.empty_like(perm); inv[perm] = np.arange(perm.size)
+    nbp = mesh.cell_neighbors[:, perm]
+    m3 = fem.Mesh(mesh.cells[:, perm], mesh.points, mesh.point_marker, np.where(nbp < 0, -1, inv[np.maximum(nbp, 0)]), 24)
+    P3 = fem.build_schur_problem(24, 2, 2, one, f_m1, u0734, mesh=m3, partition=(epart[perm], npart))
+    assert P3.sub.n_Γ == P1.sub.n_Γ and sorted(P3.sub.n_Γd) == sorted(P1.sub.n_Γd)
+    # same Schur system up to the Γ numbering: compare spectra of the assembled operators
+    def spectrum(P):
+        n = P.sub.n_Γ
+        S = np.zeros((n, n))
+        for dd in range(P.sub.ndom):
+            g = P.sub.gather_idx[dd]
+            S[np.ix_(g, g)] += P.Sd[dd]
+        return np.linalg.eigvalsh(S)
+    assert np.allclose(spectrum(P1), spectrum(P3), rtol=1e-9)
+    path = io.save_pcg_iters([15, 16, 15], "DoF576", 4, "0", 3, d)
+    assert np.array_equal(np.load(path), [15, 16, 15])

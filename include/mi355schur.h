@@ -141,6 +141,9 @@ int mi_op_apply(mi_op_t op, const double *x, double *y);
 int mi_op_bytes(mi_op_t op, int64_t *bytes_apply, int64_t *bytes_dominant_kernel);
 /* Diagnostic: launch only the dominant kernel of the apply `reps` times (x as in mi_op_apply). */
 int mi_op_apply_dominant(mi_op_t op, const double *x, int reps);
+/* Diagnostic: average duration (microseconds) of the dominant kernel over `reps` launches replayed from one
+ * graph, measured with HIP events on the context's stream (what bench.py reports as roofline.us_per_launch). */
+int mi_op_time_dominant(mi_op_t op, const double *x, int reps, double *us_per_launch);
 int mi_op_destroy(mi_op_t op);
 
 /* ---------------------------------------------------------------- BLAS-1 on the device

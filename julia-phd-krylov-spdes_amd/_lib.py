@@ -55,6 +55,7 @@ SIGNATURES = {
     "mi_op_apply": [vp, vp, vp],
     "mi_op_bytes": [vp, i64p, i64p],
     "mi_op_apply_dominant": [vp, vp, C.c_int],
+    "mi_op_time_dominant": [vp, vp, C.c_int, f64p],
     "mi_op_destroy": [vp],
     "mi_dot": [vp, i64, vp, vp, f64p],
     "mi_norm2": [vp, i64, vp, f64p],

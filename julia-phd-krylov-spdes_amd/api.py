@@ -224,6 +224,14 @@ class Operator:
         kx, px = self.ctx._ptr(x, self.n)
         check(self.ctx._L.mi_op_apply_dominant(self._h, px, C.c_int(reps)))
 
+    def time_dominant(self, x, reps: int = 200) -> float:
+        """Average microseconds per launch of the dominant kernel (HIP events, graph replay)."""
+        self.ctx._mode_for(x)
+        kx, px = self.ctx._ptr(x, self.n)
+        out = C.c_double()
+        check(self.ctx._L.mi_op_time_dominant(self._h, px, C.c_int(reps), C.byref(out)))
+        return out.value
+
     def close(self) -> None:
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
             self.ctx._L.mi_op_destroy(self._h)

@@ -110,49 +110,78 @@ __global__ __launch_bounds__(NT) void k_diag_apply(int n, const double *__restri
 // `y[rowval[k]] += nzval[k]*x[j]`, j ascending), so y is bit-identical to it.
 // Row blocks are dealt to XCDs in contiguous ranges (blockIdx % 8 selects the range) so that each
 // XCD's L2 caches one slice of x instead of all of it.
-constexpr int SPMV_TILE = 2048;
+#ifndef MI355_SPMV_TILE
+#define MI355_SPMV_TILE 1024   // 512..4096 swept on MI355X at 250k DoF: 1024 gives the shortest launch (profiles/)
+#endif
+constexpr int SPMV_TILE = MI355_SPMV_TILE;
+
+struct SpmvBlock {  // one record per row block: rows [r0, r1), non-zeros [k0, k1)
+  int r0, r1, k0, k1;
+};
 
 template <int MODE, bool DOT>  // MODE 0: y = A x, 1: y = yin - A x;  DOT: also part[b] = Σ_{rows of block b} w[r]*y[r]
-__global__ __launch_bounds__(NT) void k_spmv_csr(int nblocks, const int *__restrict__ rb,
+__global__ __launch_bounds__(NT) void k_spmv_csr(int nblocks, const SpmvBlock *__restrict__ blk,
                                                  const int *__restrict__ rowptr, const int *__restrict__ col,
                                                  const double *__restrict__ val, const double *__restrict__ x,
                                                  const double *yin, double *y, const double *__restrict__ w,
                                                  double *__restrict__ part, const int *done) {
   if (done && *done) return;
-  __shared__ double prod[SPMV_TILE];
+  __shared__ __attribute__((aligned(16))) double prod[SPMV_TILE];
   __shared__ double sm[NT / 64 + 1];
   const int per = (nblocks + 7) >> 3;
   const int b = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (b >= nblocks) return;
-  const int r0 = rb[b], r1 = rb[b + 1];
-  const int k0 = rowptr[r0], k1 = rowptr[r1];
-  const int nnz = k1 - k0;
+  const SpmvBlock bi = blk[b];
+  const int r0 = bi.r0, r1 = bi.r1, k0 = bi.k0;
+  const int nnz = bi.k1 - k0;
   double wy = 0.0;
   if (nnz <= SPMV_TILE) {
-    for (int k = threadIdx.x; k < nnz; k += NT) prod[k] = val[k0 + k] * x[col[k0 + k]];
+    // row bounds of this thread's first two rows: independent of phase 1, so issue the loads now
+    const int ra = r0 + threadIdx.x, rbb = ra + NT;
+    int a0 = 0, e0 = 0, a1 = 0, e1 = 0;
+    if (ra < r1) { a0 = rowptr[ra] - k0; e0 = rowptr[ra + 1] - k0; }
+    if (rbb < r1) { a1 = rowptr[rbb] - k0; e1 = rowptr[rbb + 1] - k0; }
+    if ((k0 & 1) == 0) {  // 16-byte aligned values, 8-byte aligned indices: two non-zeros per load
+      const int npair = (nnz + 1) >> 1;
+      for (int q = threadIdx.x; q < npair; q += NT) {
+        const int k = 2 * q;
+        if (k + 1 < nnz) {
+          const int2 c = *reinterpret_cast<const int2 *>(col + k0 + k);
+          const double2 v = *reinterpret_cast<const double2 *>(val + k0 + k);
+          *reinterpret_cast<double2 *>(&prod[k]) = make_double2(v.x * x[c.x], v.y * x[c.y]);
+        } else {
+          prod[k] = val[k0 + k] * x[col[k0 + k]];
+        }
+      }
+    } else {
+      for (int k = threadIdx.x; k < nnz; k += NT) prod[k] = val[k0 + k] * x[col[k0 + k]];
+    }
     __syncthreads();
-    for (int r = r0 + threadIdx.x; r < r1; r += NT) {
-      const int a = rowptr[r] - k0, e = rowptr[r + 1] - k0;
-      double s = 0.0;
-      for (int k = a; k < e; ++k) s += prod[k];
-      const double yr = MODE ? yin[r] - s : s;
+    for (int r = ra, i = 0; r < r1; r += NT, ++i) {
+      int a, e;
+      if (i == 0) { a = a0; e = e0; }
+      else if (i == 1) { a = a1; e = e1; }
+      else { a = rowptr[r] - k0; e = rowptr[r + 1] - k0; }
+      double sum = 0.0;
+      for (int k = a; k < e; ++k) sum += prod[k];
+      const double yr = MODE ? yin[r] - sum : sum;
       y[r] = yr;
       if (DOT) wy += w[r] * yr;
     }
   } else {
     // a single row longer than the tile (never the case for P1-FEM blocks): tile by tile,
     // thread 0 keeps the running left-to-right sum.
-    double s = 0.0;
+    double sum = 0.0;
     for (int t0 = 0; t0 < nnz; t0 += SPMV_TILE) {
       const int m = min(SPMV_TILE, nnz - t0);
       for (int k = threadIdx.x; k < m; k += NT) prod[k] = val[k0 + t0 + k] * x[col[k0 + t0 + k]];
       __syncthreads();
       if (threadIdx.x == 0)
-        for (int k = 0; k < m; ++k) s += prod[k];
+        for (int k = 0; k < m; ++k) sum += prod[k];
       __syncthreads();
     }
     if (threadIdx.x == 0) {
-      const double yr = MODE ? yin[r0] - s : s;
+      const double yr = MODE ? yin[r0] - sum : sum;
       y[r0] = yr;
       if (DOT) wy = w[r0] * yr;
     }

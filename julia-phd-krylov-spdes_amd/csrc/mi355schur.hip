@@ -319,15 +319,61 @@ int mi_op_bytes(mi_op_t op, int64_t *bytes_apply, int64_t *bytes_dominant_kernel
   return MI_OK;
 }
 
-int mi_op_apply_dominant(mi_op_t op, const double *x, int reps) {
+// Launch the dominant kernel `reps` times. With `us_per_launch` the launches are replayed from one graph
+// (eager launches of a ~5 us kernel are bound by the host's launch rate) between two HIP events recorded on the
+// context's stream, after a warm-up replay; the average duration per launch is returned.
+static int dominant_impl(mi_op_t op, const double *x, int reps, double *us_per_launch) {
   if (!op || !op->impl || !x || reps < 0) return fail(MI_ERR_BAD_ARG, "bad argument");
   return guarded([&]() -> int {
     mi_ctx_s *c = op->impl->ctx;
     c->use();
     In xi(c, x, (size_t)op->impl->n, op->hx);
-    for (int i = 0; i < reps; ++i) op->impl->apply_dominant(xi.dev);
+    if (!us_per_launch) {
+      for (int i = 0; i < reps; ++i) op->impl->apply_dominant(xi.dev);
+      return MI_OK;
+    }
+    *us_per_launch = 0.0;
+    if (reps == 0) return MI_OK;
+    hipStream_t s = c->stream;
+    hipGraph_t gr = nullptr;
+    MI_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    try {
+      for (int i = 0; i < reps; ++i) op->impl->apply_dominant(xi.dev);
+    } catch (...) {
+      (void)hipStreamEndCapture(s, &gr);
+      if (gr) (void)hipGraphDestroy(gr);
+      throw;
+    }
+    MI_HIP(hipStreamEndCapture(s, &gr));
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(gr);
+    if (e != hipSuccess) raise(MI_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.f;
+    e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipGraphLaunch(ex, s);           // warm-up replay
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipEventRecord(e0, s);
+    if (e == hipSuccess) e = hipGraphLaunch(ex, s);
+    if (e == hipSuccess) e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipGraphExecDestroy(ex);
+    if (e != hipSuccess) raise(MI_ERR_HIP, "timed replay failed: %s", hipGetErrorString(e));
+    *us_per_launch = (double)ms * 1e3 / reps;
     return MI_OK;
   });
+}
+
+int mi_op_apply_dominant(mi_op_t op, const double *x, int reps) { return dominant_impl(op, x, reps, nullptr); }
+
+int mi_op_time_dominant(mi_op_t op, const double *x, int reps, double *us_per_launch) {
+  if (!us_per_launch) return fail(MI_ERR_BAD_ARG, "us_per_launch is NULL");
+  return dominant_impl(op, x, reps, us_per_launch);
 }
 
 int mi_op_destroy(mi_op_t op) {

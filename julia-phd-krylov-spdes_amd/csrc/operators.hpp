@@ -105,29 +105,36 @@ inline void append_block(HostCsr &a, const HostCsr &b, int col_shift, int new_co
 struct CsrDev {
   int n_rows = 0, n_cols = 0, nblocks = 0;
   int64_t nnz = 0;
-  DevBuf<int> rowptr, col, rb;
+  DevBuf<int> rowptr, col;
+  DevBuf<SpmvBlock> blk;
   DevBuf<double> val;
   void upload(const HostCsr &h, hipStream_t s) {
     n_rows = h.n_rows; n_cols = h.n_cols; nnz = h.nnz();
-    std::vector<int> blocks{0};
+    // Greedy row blocks of <= SPMV_TILE non-zeros (a longer row stands alone). A block prefers to start at
+    // an even non-zero offset (paired loads in the kernel): if the greedy end lands on an odd offset, give
+    // back up to three rows to reach an even one.
+    std::vector<SpmvBlock> blocks;
     int r = 0;
-    while (r < n_rows) {  // greedy row blocks of <= SPMV_TILE non-zeros (a longer row stands alone)
+    while (r < n_rows) {
       int e = r + 1;
       while (e < n_rows && h.rowptr[e + 1] - h.rowptr[r] <= SPMV_TILE) ++e;
-      blocks.push_back(e);
+      if (e < n_rows && (h.rowptr[e] & 1))
+        for (int back = 1; back <= 3 && e - back > r; ++back)
+          if ((h.rowptr[e - back] & 1) == 0) { e -= back; break; }
+      blocks.push_back(SpmvBlock{r, e, h.rowptr[r], h.rowptr[e]});
       r = e;
     }
-    nblocks = (int)blocks.size() - 1;
+    nblocks = (int)blocks.size();
     std::vector<int> rp = h.rowptr;
     if (rp.empty()) rp.push_back(0);
-    rowptr.upload(rp, s); col.upload(h.col, s); val.upload(h.val, s); rb.upload(blocks, s);
+    rowptr.upload(rp, s); col.upload(h.col, s); val.upload(h.val, s); blk.upload(blocks, s);
   }
   // y = A x (mode 0) or y = yin - A x (mode 1); with `w`: also part[b] = Σ w[r] y[r] over the rows of block b
   void launch(int mode, const double *x, const double *yin, double *y, const int *done, hipStream_t s,
               const double *w = nullptr, double *part = nullptr) const {
     if (nblocks == 0) return;
     const int grid = ((nblocks + 7) / 8) * 8;
-#define MI_SPMV(M, D) hipLaunchKernelGGL((k_spmv_csr<M, D>), dim3(grid), dim3(NT), 0, s, nblocks, rb.p, rowptr.p, col.p, val.p, x, yin, y, w, part, done)
+#define MI_SPMV(M, D) hipLaunchKernelGGL((k_spmv_csr<M, D>), dim3(grid), dim3(NT), 0, s, nblocks, blk.p, rowptr.p, col.p, val.p, x, yin, y, w, part, done)
     if (mode == 0) { if (w) MI_SPMV(0, true); else MI_SPMV(0, false); }
     else           { if (w) MI_SPMV(1, true); else MI_SPMV(1, false); }
 #undef MI_SPMV

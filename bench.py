@@ -80,6 +80,20 @@ def bench_full_system(args):
     Aop.apply_dominant(bd, reps=20); ctx.synchronize()
     reps = max(args.kernel_reps, 50)
     us = kernel_us(api, ctx, Aop, bd, reps)
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        cores = orc.set_threads(min(len(os.sched_getaffinity(0)), 16))
+        Ao, Mo = orc.csc_operator(A, gather=True), orc.jacobi_operator(A.diagonal())
+        xo, ito, reso = orc.pcg(Ao, b, np.zeros(n), Mo, eps=args.eps)
+        assert abs(ito - it) <= max(2, it // 100), f"GPU it={it}, oracle it={ito}"   # ~900-iteration CG: see DESIGN.md §3
+        nsolve, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0:
+            orc.pcg(Ao, b, np.zeros(n), Mo, eps=args.eps)
+            nsolve += 1
+        tc = time.perf_counter() - t0
+        cpu = {"value": round(nsolve * (ito - 1) / tc, 1), "unit": "iterations/s", "cores": cores, "kind": "port",
+               "sample": f"{nsolve} full Jacobi-PCG solves of the same system in {tc:.1f}s (C restatement, OpenMP row-gather SpMV; not Julia)"}
     out = {"metric": "full-A Jacobi-PCG iterations/sec, 250k DoF (configs[1])", "value": round(steps * (it - 1) / el, 1),
            "unit": "iterations/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(el / steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -88,7 +102,7 @@ def bench_full_system(args):
            "roofline": {"bound": "hbm", "kernel": "k_spmv_csr", "achieved": round(nb / us / 1e3, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(nb / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
                         "bytes_per_launch": int(nb), "us_per_launch": round(us, 3)},
-           "cpu_baseline": None}
+           "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
 
 
@@ -278,7 +292,7 @@ def main():
                                    f"({args.px}x{args.py} boxes), lognormal a=exp(g) seed {args.seed}, n_Γ={n_Γ}; "
                                    f"pcg(S, b_schur, 0, ΠSnn), eps={args.eps:g}",
                        "subdomains_per_gpu": hi - lo, "it": its, "loop_iterations_per_solve": loop_its,
-                       "final_relres": relres, "graph_chunk": args.chunk},
+                       "final_relres": relres, "launches_per_iteration": 2 if folded else 4},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -143,9 +143,10 @@ struct mi_ctx_s {
   // solver workspaces keyed by problem size; graphs keyed inside
   std::map<int64_t, std::unique_ptr<mi::SolverWorkspace>> workspaces;
   void use() const { MI_HIP(hipSetDevice(device)); }
-  void allreduce(double *buf, size_t n) {
+  void allreduce(double *buf, size_t n) { allreduce(buf, buf, n); }
+  void allreduce(const double *send, double *recv, size_t n) {
     if (comm)  // also with n_ranks == 1, so that a single-GPU box exercises the captured collective
-      MI_NCCL(mi::Rccl::get().AllReduce(buf, buf, n, ncclDouble, ncclSum, comm, stream));
+      MI_NCCL(mi::Rccl::get().AllReduce(send, recv, n, ncclDouble, ncclSum, comm, stream));
   }
 };
 

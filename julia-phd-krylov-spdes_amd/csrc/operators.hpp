@@ -267,6 +267,7 @@ struct DenseBlockOp : Operator {
   bool scale;  // true: Neumann-Neumann (gather r/cnt, result /cnt)
   int rpw, waves, ntiles = 0, max_nd = 0;  // rows per wave, waves per workgroup (4 or 8)
   DevBuf<double> M, cnt, yslots;
+  DevBuf<double> yslots_all;  // multi-GPU: all-reduced copy of the contribution slots (every rank's subdomains)
   DevBuf<double> fold_part0, fold_part1;  // per-tile partial dots of the folded PCG launches
   DevBuf<double> fold_con, fold_vec;      // [nloc*W] local-order contributions; [4*nloc] r/p current+next copies
   DevBuf<GemvTile> tiles;
@@ -318,7 +319,9 @@ struct DenseBlockOp : Operator {
     }
     tiles.upload(tv, c->stream);
     yslots.alloc((size_t)n_gamma * maps.slot_width + 4);
-    yslots.zero(c->stream);  // unused slots stay 0 for the lifetime of the operator
+    yslots.zero(c->stream);  // unused slots (and, multi-GPU, the other ranks' slots) stay 0 for the lifetime of the operator
+    yslots_all.alloc((size_t)n_gamma * maps.slot_width + 4);
+    yslots_all.zero(c->stream);
     fold_part0.alloc((size_t)ntiles + 1); fold_part1.alloc((size_t)ntiles + 1);
     fold_part0.zero(c->stream); fold_part1.zero(c->stream);
     fold_con.alloc((size_t)maps.nloc * maps.slot_width + 4); fold_con.zero(c->stream);
@@ -365,9 +368,13 @@ struct DenseBlockOp : Operator {
            maps.nd == o.maps.nd && maps.gidx_h == o.maps.gidx_h;
   }
   AsmView apply_view(const double *x, double *y, const int *done) override {
-    if (ctx->comm) return Operator::apply_view(x, y, done);  // the Γ-sum must be materialised for the all-reduce
     gemv(x, done);
-    return AsmView{yslots.p, maps.slot_width};
+    if (!ctx->comm) return AsmView{yslots.p, maps.slot_width};
+    // Multi-GPU: every rank wrote only its own subdomains' slots (the rest are zero), so the out-of-place sum
+    // over ranks IS the full slot table (x + 0 is exact): the consumer then takes the Γ-sum in the same
+    // ascending-subdomain order as on one GPU, and no separate assemble launch is needed.
+    ctx->allreduce(yslots.p, yslots_all.p, (size_t)n * maps.slot_width);
+    return AsmView{yslots_all.p, maps.slot_width};
   }
   void bytes(int64_t *a, int64_t *d) const override { *a = alg_bytes + 8 * n; *d = alg_bytes; }
   void apply_dominant(const double *x) override { gemv(x, nullptr); }

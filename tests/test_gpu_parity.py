@@ -290,7 +290,20 @@ def test_rccl_single_rank_communicator(pkg, ctx, orc, micro):
     assert np.array_equal(c2.allreduce_sum(v.copy()), v)
     S, M = gpu_ops(pkg, c2, P)
     So, Mo = orc_ops(orc, P)
-    assert_history(api.pcg(S, P.b_schur, np.zeros(P.sub.n_Γ), M), orc.pcg(So, P.b_schur, np.zeros(P.sub.n_Γ), Mo))
+    got = api.pcg(S, P.b_schur, np.zeros(P.sub.n_Γ), M)
+    assert_history(got, orc.pcg(So, P.b_schur, np.zeros(P.sub.n_Γ), Mo))
+    # With a communicator the Γ-sums go through the all-reduced slot table and the 4-launch loop; summing with the
+    # other ranks' zeros is exact, so the result is bit-identical to the same loop without a communicator.
+    import os
+    S1, M1 = gpu_ops(pkg, ctx, P)
+    os.environ["MI355_NO_FOLD"] = "1"
+    try:
+        ref = api.pcg(S1, P.b_schur, np.zeros(P.sub.n_Γ), M1)
+    finally:
+        del os.environ["MI355_NO_FOLD"]
+    assert got[1] == ref[1] and np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0])
+    v = np.random.default_rng(1).standard_normal(P.sub.n_Γ)
+    assert np.array_equal(S * v, S1 * v) and np.array_equal(M.ldiv(v), M1.ldiv(v))
 
 
 # ------------------------------------------------------------------ folded PCG (2 launches / iteration) vs the other loop forms

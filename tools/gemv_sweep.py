@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sweep the batched-GEMV kernel variants (rows per wave, load pipelining) on the 1M-DoF blocks and
+"""Sweep the batched-GEMV kernel variants (waves per workgroup, rows per wave) on the 1M-DoF blocks and
 report us/launch and algorithmic GB/s for the S-apply and the NN-apply, plus PCG time per solve."""
 import os
 import sys
@@ -22,19 +22,15 @@ P = fem.build_schur_problem(N, 4, 2, np.exp(g), lambda x, y: -1.0 + 0 * x, lambd
 ctx = api.Context(0)
 b = torch.from_numpy(P.b_schur).cuda()
 n = P.sub.n_Γ
-for rpw in (1, 2, 4):
-    for pipe in (0, 1):
-        os.environ["MI355_GEMV_RPW"], os.environ["MI355_GEMV_PIPE"] = str(rpw), str(pipe)
+for waves in (4, 8, 16):
+    for rpw in (1, 2, 4):
+        os.environ["MI355_GEMV_WAVES"], os.environ["MI355_GEMV_RPW"] = str(waves), str(rpw)
         S = api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt)
         M = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)
         out = []
         for op in (S, M):
             _, nb = op.bytes()
-            e0, e1 = api.Event(ctx), api.Event(ctx)
-            op.apply_dominant(b, reps=30)
-            ctx.synchronize()
-            e0.record(); op.apply_dominant(b, reps=300); e1.record()
-            us = e0.elapsed_ms(e1) / 300 * 1e3
+            us = op.time_dominant(b, 300)
             out.append((us, nb / us / 1e3))
         for _ in range(5):
             x, it, res = api.pcg(S, b, torch.zeros_like(b), M)
@@ -44,6 +40,6 @@ for rpw in (1, 2, 4):
         for k in range(100):
             api.pcg(S, b, xs[k], M)
         dt = (time.perf_counter() - t0) / 100
-        print(f"rpw={rpw} pipe={pipe}: S {out[0][0]:6.2f} us {out[0][1]:7.1f} GB/s | NN {out[1][0]:6.2f} us {out[1][1]:7.1f} GB/s"
+        print(f"waves={waves} rpw={rpw}: S {out[0][0]:6.2f} us {out[0][1]:7.1f} GB/s | NN {out[1][0]:6.2f} us {out[1][1]:7.1f} GB/s"
               f" | pcg it={it} {dt * 1e6:7.1f} us/solve {(it - 1) / dt:8.0f} it/s", flush=True)
         del S, M

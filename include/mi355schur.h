@@ -125,6 +125,21 @@ int mi_schur_matfree_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const i
                             mi_interior_solve_fn solve, void *user, int index_base,
                             int64_t dom_begin, int64_t dom_end, mi_op_t *op);
 
+/* mi_schur_matfree_device_create — the same operator with the interior solve ON THE DEVICE, as the reference
+ * does it: `IterativeSolvers.cg(A_IIdd, A_IΓdd*xd, reltol=reltol)` from a zero initial guess (EPDD.jl:648-650,
+ * default reltol 1e-9; no preconditioner — the reference's AMG `Pl` is out of scope). All local subdomains are
+ * iterated together on the block-diagonal A_II with per-subdomain scalars; a subdomain stops when its residual
+ * is <= reltol * ||rhs|| or after n_i iterations.
+ *   A_IIdd[d]: CSC arrays of the symmetric n_i[d] x n_i[d] interior block. */
+int mi_schur_matfree_device_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d,
+                                   const int64_t *n_i, const int64_t *const *gather_idx,
+                                   const int64_t *const *ii_colptr, const int64_t *const *ii_rowval,
+                                   const double *const *ii_nzval, const int64_t *const *ig_colptr,
+                                   const int64_t *const *ig_rowval, const double *const *ig_nzval,
+                                   const int64_t *const *gg_colptr, const int64_t *const *gg_rowval,
+                                   const double *const *gg_nzval, double reltol, int index_base,
+                                   int64_t dom_begin, int64_t dom_end, mi_op_t *op);
+
 /* mi_schur_global_create — `apply_global_schur(A_IId, A_IΓd, A_ΓΓ, x)`, EPDD.jl:596-625:
  * Sx = A_ΓΓ x − Σ_d A_IΓd' (A_IId^{-1} (A_IΓd x)), Γ-global column indices (no gather maps).
  *   A_IΓd[d]: CSC arrays of the n_i[d] x n_gamma block;  A_ΓΓ: CSC arrays, symmetric. */

@@ -366,11 +366,13 @@ def _csc_parts(mats, lo, hi):
 
 
 class MatrixFreeLocalSchurs(Operator):
-    """`x -> apply_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γd_Γ2l, node_Γ_cnt, x; preconds)` (EPDD.jl:711-747),
-    the closure of Example03:143-150. Sparse products on the device, `A_IIdd^{-1}` through `interior_solvers`."""
+    """`x -> apply_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γd_Γ2l, node_Γ_cnt, x; preconds, reltol)` (EPDD.jl:711-747),
+    the closure of Example03:143-150. Sparse products on the device; `A_IIdd^{-1}` either through
+    `interior_solvers[d](rhs)` on the host, or — `interior_solvers=None` — by the device CG that restates the
+    reference's own `IterativeSolvers.cg(A_IIdd, rhs, reltol=reltol)` (EPDD.jl:648-650)."""
 
-    def __init__(self, ctx: Context, A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γd_Γ2l, node_Γ_cnt, interior_solvers,
-                 dom_slice=None):
+    def __init__(self, ctx: Context, A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γd_Γ2l, node_Γ_cnt, interior_solvers=None,
+                 reltol: float = 1e-9, dom_slice=None):
         ndom = len(A_IΓdd)
         n_Γ = len(node_Γ_cnt)
         lo, hi = _dom_slice(ctx, ndom, dom_slice)
@@ -379,8 +381,17 @@ class MatrixFreeLocalSchurs(Operator):
         ni = _i64([A.shape[0] for A in A_IIdd])
         igp, igi, igv = _csc_parts(A_IΓdd, lo, hi)
         ggp, ggi, ggv = _csc_parts(A_ΓΓdd, lo, hi)
-        cb = _wrap_interior(interior_solvers)
         h = vp()
+        if interior_solvers is None:
+            iip, iii, iiv = _csc_parts(A_IIdd, lo, hi)
+            check(ctx._L.mi_schur_matfree_device_create(
+                ctx._h, i64(ndom), i64(n_Γ), nd.ctypes.data_as(i64p), ni.ctypes.data_as(i64p), _ptrs(g, i64p),
+                _ptrs(iip, i64p), _ptrs(iii, i64p), _ptrs(iiv, f64p), _ptrs(igp, i64p), _ptrs(igi, i64p), _ptrs(igv, f64p),
+                _ptrs(ggp, i64p), _ptrs(ggi, i64p), _ptrs(ggv, f64p), C.c_double(reltol), C.c_int(0), i64(lo), i64(hi),
+                C.byref(h)))
+            super().__init__(ctx, h)
+            return
+        cb = _wrap_interior(interior_solvers)
         check(ctx._L.mi_schur_matfree_create(
             ctx._h, i64(ndom), i64(n_Γ), nd.ctypes.data_as(i64p), ni.ctypes.data_as(i64p), _ptrs(g, i64p),
             _ptrs(igp, i64p), _ptrs(igi, i64p), _ptrs(igv, f64p), _ptrs(ggp, i64p), _ptrs(ggi, i64p), _ptrs(ggv, f64p),

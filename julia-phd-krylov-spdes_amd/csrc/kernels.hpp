@@ -192,6 +192,104 @@ __global__ __launch_bounds__(NT) void k_spmv_csr(int nblocks, const SpmvBlock *_
   }
 }
 
+// ------------------------------------------------------------------ interior CG on the device
+// The reference's matrix-free Schur applies solve A_IIdd v = A_IΓdd xd with `IterativeSolvers.cg(A, b; reltol)`
+// (EPDD.jl:648-650; third-party, restated from its published iteration, IterativeSolvers.jl cg.jl `CGIterable`):
+//     x = 0, r = b, u = 0, residual = ||r||, prev_residual = 1, tol = reltol*residual, maxiter = n
+//     while residual > tol and iteration < maxiter:
+//         beta = residual^2 / prev_residual^2;  u = r + beta u;  c = A u
+//         alpha = residual^2 / (u'c);  x += alpha u;  r -= alpha c;  prev_residual = residual;  residual = ||r||
+// All local subdomains are solved at once on the block-diagonal A_II with per-subdomain scalars; row blocks never
+// straddle subdomains. One iteration = k_spmv_csr<0,true> (c = A u with the u'c partials) + k_icg_update +
+// k_icg_direction. Per-subdomain scalars are double-buffered (cur/nxt) so no launch reads what it writes;
+// a converged subdomain is frozen (its workgroups return), the others keep iterating.
+struct IcgMeta {
+  const SpmvBlock *blk;
+  const int *blk_dom;          // subdomain of every row block
+  const int *dom_b0, *dom_b1;  // row-block range of every subdomain
+  double *res_cur, *res_nxt;   // residual norms
+  double *tol;
+  int *done_cur, *done_nxt, *iters;
+  int maxiter_cap;             // 0: maxiter = n_i of the subdomain
+};
+__device__ __forceinline__ double icg_dom_sum(const double *part, int b0, int b1, double *sm) {
+  double v = 0.0;
+  for (int i = b0 + (int)threadIdx.x; i < b1; i += NT) v += part[i];
+  return block_sum(v, sm);
+}
+// r = rhs; x = 0; u = r (beta*0); partial r'r
+__global__ __launch_bounds__(NT) void k_icg_init(IcgMeta m, const double *__restrict__ rhs, double *__restrict__ x,
+                                                 double *__restrict__ r, double *__restrict__ u,
+                                                 double *__restrict__ p_rr) {
+  __shared__ double sm[NT / 64 + 1];
+  const SpmvBlock bi = m.blk[blockIdx.x];
+  double s = 0.0;
+  for (int i = bi.r0 + threadIdx.x; i < bi.r1; i += NT) {
+    const double v = rhs[i];
+    r[i] = v; u[i] = v; x[i] = 0.0;
+    s += v * v;
+  }
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) p_rr[blockIdx.x] = s;
+}
+// one workgroup per subdomain: residual = ||b||, tol = reltol*residual, flags
+__global__ __launch_bounds__(NT) void k_icg_start(IcgMeta m, const double *__restrict__ p_rr, double reltol) {
+  __shared__ double sm[NT / 64 + 1];
+  const int d = blockIdx.x;
+  const double rr = icg_dom_sum(p_rr, m.dom_b0[d], m.dom_b1[d], sm);
+  if (threadIdx.x == 0) {
+    const double res = sqrt(rr);
+    m.res_cur[d] = res; m.res_nxt[d] = res;
+    m.tol[d] = reltol * res;
+    m.iters[d] = 0;
+    const int dn = res <= m.tol[d];
+    m.done_cur[d] = dn; m.done_nxt[d] = dn;
+  }
+}
+// alpha = residual^2 / (u'c); x += alpha u; r -= alpha c; partial r'r
+__global__ __launch_bounds__(NT) void k_icg_update(IcgMeta m, const double *__restrict__ p_uc, const double *__restrict__ u,
+                                                   const double *__restrict__ c, double *__restrict__ x,
+                                                   double *__restrict__ r, double *__restrict__ p_rr) {
+  __shared__ double sm[NT / 64 + 1];
+  const int b = blockIdx.x, d = m.blk_dom[b];
+  const bool lead = b == m.dom_b0[d] && threadIdx.x == 0;
+  if (m.done_nxt[d]) { if (lead) m.done_cur[d] = 1; return; }
+  const double uc = icg_dom_sum(p_uc, m.dom_b0[d], m.dom_b1[d], sm);
+  const double res = m.res_nxt[d];
+  const double alpha = (res * res) / uc;
+  const SpmvBlock bi = m.blk[b];
+  double s = 0.0;
+  for (int i = bi.r0 + threadIdx.x; i < bi.r1; i += NT) {
+    x[i] = x[i] + alpha * u[i];
+    const double ri = r[i] - alpha * c[i];
+    r[i] = ri;
+    s += ri * ri;
+  }
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) p_rr[b] = s;
+  if (lead) { m.res_cur[d] = res; m.done_cur[d] = 0; }
+}
+// residual = ||r||; beta = residual^2 / prev_residual^2; u = r + beta u; iteration count and stop test
+__global__ __launch_bounds__(NT) void k_icg_direction(IcgMeta m, const double *__restrict__ p_rr,
+                                                      const double *__restrict__ r, double *__restrict__ u,
+                                                      const int *__restrict__ n_i) {
+  __shared__ double sm[NT / 64 + 1];
+  const int b = blockIdx.x, d = m.blk_dom[b];
+  if (m.done_cur[d]) return;
+  const double rr = icg_dom_sum(p_rr, m.dom_b0[d], m.dom_b1[d], sm);
+  const double res = sqrt(rr), prev = m.res_cur[d];
+  const double beta = (res * res) / (prev * prev);
+  const SpmvBlock bi = m.blk[b];
+  for (int i = bi.r0 + threadIdx.x; i < bi.r1; i += NT) u[i] = r[i] + beta * u[i];
+  if (b == m.dom_b0[d] && threadIdx.x == 0) {
+    const int it = m.iters[d] + 1;
+    m.iters[d] = it;
+    m.res_nxt[d] = res;
+    const int maxiter = m.maxiter_cap > 0 ? m.maxiter_cap : n_i[d];
+    m.done_nxt[d] = (res <= m.tol[d]) || (it >= maxiter);
+  }
+}
+
 // ------------------------------------------------------------------ batched dense GEMV with fused gather
 // y_d = M_d * (D_d R_d x)  [* D_d], for all subdomains d of this rank in one launch.
 //   S-apply  (SCALE=false): M_d = S_d,  EPDD.jl:775-778  (gather, `Sd[idom]*xd`)

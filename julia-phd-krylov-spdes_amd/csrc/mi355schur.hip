@@ -282,6 +282,20 @@ int mi_schur_matfree_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const i
                                         gg_colptr, gg_rowval, gg_nzval, solve, user, index_base, dom_begin, dom_end));
 }
 
+int mi_schur_matfree_device_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d,
+                                   const int64_t *n_i, const int64_t *const *gather_idx,
+                                   const int64_t *const *ii_colptr, const int64_t *const *ii_rowval,
+                                   const double *const *ii_nzval, const int64_t *const *ig_colptr,
+                                   const int64_t *const *ig_rowval, const double *const *ig_nzval,
+                                   const int64_t *const *gg_colptr, const int64_t *const *gg_rowval,
+                                   const double *const *gg_nzval, double reltol, int index_base, int64_t dom_begin,
+                                   int64_t dom_end, mi_op_t *op) {
+  if (!ii_colptr) return fail(MI_ERR_BAD_ARG, "A_II arrays are NULL");
+  MI_NEW_OP(ctx, op, new MatfreeSchurOp(ctx, ndom, n_gamma, n_gamma_d, n_i, gather_idx, ig_colptr, ig_rowval, ig_nzval,
+                                        gg_colptr, gg_rowval, gg_nzval, nullptr, nullptr, index_base, dom_begin, dom_end,
+                                        ii_colptr, ii_rowval, ii_nzval, reltol));
+}
+
 int mi_schur_global_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_i,
                            const int64_t *const *ig_colptr, const int64_t *const *ig_rowval,
                            const double *const *ig_nzval, const int64_t *gg_colptr, const int64_t *gg_rowval,

@@ -108,23 +108,29 @@ struct CsrDev {
   DevBuf<int> rowptr, col;
   DevBuf<SpmvBlock> blk;
   DevBuf<double> val;
-  void upload(const HostCsr &h, hipStream_t s) {
+  std::vector<SpmvBlock> blocks_h;
+  // `breaks` (ascending row indices): a row block never crosses one of them (per-subdomain partial sums)
+  void upload(const HostCsr &h, hipStream_t s, const std::vector<int> *breaks = nullptr) {
     n_rows = h.n_rows; n_cols = h.n_cols; nnz = h.nnz();
     // Greedy row blocks of <= SPMV_TILE non-zeros (a longer row stands alone). A block prefers to start at
     // an even non-zero offset (paired loads in the kernel): if the greedy end lands on an odd offset, give
     // back up to three rows to reach an even one.
     std::vector<SpmvBlock> blocks;
     int r = 0;
+    size_t nb = 0;
     while (r < n_rows) {
+      while (breaks && nb < breaks->size() && (*breaks)[nb] <= r) ++nb;
+      const int limit = (breaks && nb < breaks->size()) ? std::min((*breaks)[nb], n_rows) : n_rows;
       int e = r + 1;
-      while (e < n_rows && h.rowptr[e + 1] - h.rowptr[r] <= SPMV_TILE) ++e;
-      if (e < n_rows && (h.rowptr[e] & 1))
+      while (e < limit && h.rowptr[e + 1] - h.rowptr[r] <= SPMV_TILE) ++e;
+      if (e < limit && (h.rowptr[e] & 1))
         for (int back = 1; back <= 3 && e - back > r; ++back)
           if ((h.rowptr[e - back] & 1) == 0) { e -= back; break; }
       blocks.push_back(SpmvBlock{r, e, h.rowptr[r], h.rowptr[e]});
       r = e;
     }
     nblocks = (int)blocks.size();
+    blocks_h = blocks;
     std::vector<int> rp = h.rowptr;
     if (rp.empty()) rp.push_back(0);
     rowptr.upload(rp, s); col.upload(h.col, s); val.upload(h.val, s); blk.upload(blocks, s);
@@ -399,9 +405,96 @@ struct HostStage {
   ~HostStage() { release(); }
 };
 
+// ------------------------------------------------------------------ interior CG on the device (kernels.hpp, IcgMeta)
+struct InteriorCg {
+  mi_ctx_s *ctx = nullptr;
+  CsrDev A;  // block-diagonal A_II of the local subdomains
+  int ndl = 0, n = 0, chunk = 64;
+  double reltol = 1e-9;
+  DevBuf<double> u, c, r, p_uc, p_rr, res_cur, res_nxt, tol;
+  DevBuf<int> blk_dom, dom_b0, dom_b1, done_cur, done_nxt, iters, n_i;
+  int *done_host = nullptr;
+  hipGraphExec_t graph = nullptr;
+  double *graph_x = nullptr;
+  IcgMeta meta{};
+  long long total_iterations = 0;  // statistics: iterations of the slowest subdomain, summed over solves
+
+  void build(mi_ctx_s *c_, const HostCsr &a, const std::vector<int> &ioff, const std::vector<int> &ni, double reltol_) {
+    ctx = c_; reltol = reltol_; ndl = (int)ni.size(); n = a.n_rows;
+    std::vector<int> breaks(ioff.begin(), ioff.end());
+    A.upload(a, ctx->stream, &breaks);
+    std::vector<int> bd(A.nblocks), b0(ndl, 0), b1(ndl, 0);
+    int d = 0;
+    for (int b = 0; b < A.nblocks; ++b) {
+      while (d + 1 < ndl && A.blocks_h[b].r0 >= ioff[d + 1]) ++d;
+      bd[b] = d;
+    }
+    for (int dd = 0; dd < ndl; ++dd) { b0[dd] = A.nblocks; b1[dd] = 0; }
+    for (int b = 0; b < A.nblocks; ++b) { b0[bd[b]] = std::min(b0[bd[b]], b); b1[bd[b]] = std::max(b1[bd[b]], b + 1); }
+    for (int dd = 0; dd < ndl; ++dd) if (b0[dd] > b1[dd]) b0[dd] = b1[dd] = 0;  // empty interior
+    blk_dom.upload(bd, ctx->stream); dom_b0.upload(b0, ctx->stream); dom_b1.upload(b1, ctx->stream);
+    n_i.upload(ni, ctx->stream);
+    u.alloc(n + 1); c.alloc(n + 1); r.alloc(n + 1);
+    p_uc.alloc(A.nblocks + 1); p_rr.alloc(A.nblocks + 1);
+    res_cur.alloc(ndl + 1); res_nxt.alloc(ndl + 1); tol.alloc(ndl + 1);
+    done_cur.alloc(ndl + 1); done_nxt.alloc(ndl + 1); iters.alloc(ndl + 1);
+    MI_HIP(hipHostMalloc((void **)&done_host, sizeof(int) * (ndl + 1)));
+    chunk = std::max(1, env_int("MI355_ICG_CHUNK", 64));
+    meta = IcgMeta{A.blk.p, blk_dom.p, dom_b0.p, dom_b1.p, res_cur.p, res_nxt.p, tol.p, done_cur.p, done_nxt.p, iters.p, 0};
+  }
+  ~InteriorCg() {
+    if (graph) (void)hipGraphExecDestroy(graph);
+    if (done_host) (void)hipHostFree(done_host);
+  }
+  void iteration(double *x) {
+    hipStream_t s = ctx->stream;
+    A.launch(0, u.p, nullptr, c.p, nullptr, s, u.p, p_uc.p);  // c = A u, partial u'c
+    hipLaunchKernelGGL(k_icg_update, dim3(A.nblocks), dim3(NT), 0, s, meta, p_uc.p, u.p, c.p, x, r.p, p_rr.p);
+    hipLaunchKernelGGL(k_icg_direction, dim3(A.nblocks), dim3(NT), 0, s, meta, p_rr.p, r.p, u.p, n_i.p);
+    MI_HIP(hipGetLastError());
+  }
+  // x = A_II^{-1} rhs for every local subdomain (device pointers), to the relative tolerance
+  void solve(const double *rhs, double *x) {
+    if (A.nblocks == 0) return;
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(k_icg_init, dim3(A.nblocks), dim3(NT), 0, s, meta, rhs, x, r.p, u.p, p_rr.p);
+    hipLaunchKernelGGL(k_icg_start, dim3(ndl), dim3(NT), 0, s, meta, p_rr.p, reltol);
+    MI_HIP(hipGetLastError());
+    if (!graph || graph_x != x) {  // `chunk` iterations per replay
+      if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
+      hipGraph_t gr = nullptr;
+      MI_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      try {
+        for (int k = 0; k < chunk; ++k) iteration(x);
+      } catch (...) {
+        (void)hipStreamEndCapture(s, &gr);
+        if (gr) (void)hipGraphDestroy(gr);
+        throw;
+      }
+      MI_HIP(hipStreamEndCapture(s, &gr));
+      hipError_t e = hipGraphInstantiate(&graph, gr, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(gr);
+      if (e != hipSuccess) raise(MI_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+      graph_x = x;
+    }
+    const long long max_replays = (long long)n / chunk + 2;  // maxiter = size(A, 2)
+    for (long long l = 0; l <= max_replays; ++l) {
+      MI_HIP(hipMemcpyAsync(done_host, done_nxt.p, sizeof(int) * ndl, hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+      bool all = true;
+      for (int d = 0; d < ndl; ++d) all = all && done_host[d];
+      if (all) break;
+      MI_HIP(hipGraphLaunch(graph, s));
+      total_iterations += chunk;
+    }
+  }
+};
+
 // ------------------------------------------------------------------ matrix-free local Schur operator (EPDD.jl:711-747)
 // All local subdomains are stacked into block-diagonal CSR matrices over the concatenated local
 // spaces, so one SpMV launch serves every subdomain: rhs = A_IΓ xd ; t = A_ΓΓ xd ; yloc = t - A_ΓI v.
+// v = A_II^{-1} rhs is either the host callback (north_star: interior solve on the host) or the device CG
+// above (the reference's own inexact `IterativeSolvers.cg(A_IIdd, rhs; reltol)`).
 struct MatfreeSchurOp : Operator {
   LocalMaps maps;
   CsrDev A_IG, A_GI, A_GG;
@@ -409,18 +502,22 @@ struct MatfreeSchurOp : Operator {
   int64_t d0;
   int ni_tot = 0;
   mi_interior_solve_fn solve; void *user;
+  std::unique_ptr<InteriorCg> icg;
   DevBuf<double> xcat, rhs, sol, t1, yloc;
   HostStage stage;
 
   MatfreeSchurOp(mi_ctx_s *c, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d, const int64_t *n_i,
                  const int64_t *const *gather_idx, const int64_t *const *ig_ptr, const int64_t *const *ig_idx,
                  const double *const *ig_val, const int64_t *const *gg_ptr, const int64_t *const *gg_idx,
-                 const double *const *gg_val, mi_interior_solve_fn f, void *u, int base, int64_t d0_, int64_t d1)
+                 const double *const *gg_val, mi_interior_solve_fn f, void *u, int base, int64_t d0_, int64_t d1,
+                 const int64_t *const *ii_ptr = nullptr, const int64_t *const *ii_idx = nullptr,
+                 const double *const *ii_val = nullptr, double reltol = 1e-9)
       : Operator(c, n_gamma), d0(d0_), solve(f), user(u) {
-    if (!f || !n_i || !ig_ptr || !ig_idx || !ig_val || !gg_ptr || !gg_idx || !gg_val)
+    if ((!f && !ii_ptr) || !n_i || !ig_ptr || !ig_idx || !ig_val || !gg_ptr || !gg_idx || !gg_val)
       raise(MI_ERR_BAD_ARG, "mi_schur_matfree_create: NULL argument");
+    if (ii_ptr && (!ii_idx || !ii_val || !(reltol > 0.0))) raise(MI_ERR_BAD_ARG, "device interior: bad A_II arrays / reltol");
     maps.build(c, ndom, n_gamma, n_gamma_d, gather_idx, base, d0, d1);
-    HostCsr ig, gi, gg;
+    HostCsr ig, gi, gg, ii;
     int64_t itot = 0;
     for (int dl = 0; dl < maps.ndl; ++dl) { ioff.push_back((int)itot); ni.push_back((int)n_i[d0 + dl]); itot += n_i[d0 + dl]; }
     if (itot >= INT32_MAX) raise(MI_ERR_BAD_ARG, "interior too large");
@@ -434,12 +531,18 @@ struct MatfreeSchurOp : Operator {
       append_block(gi, gi_d, ioff[dl], ni_tot);
       append_block(ig, ig_d, maps.loc_off[dl], maps.nloc);
       append_block(gg, gg_d, maps.loc_off[dl], maps.nloc);
+      if (ii_ptr) append_block(ii, host_csr(ni[dl], ni[dl], ii_ptr[d], ii_idx[d], ii_val[d], base), ioff[dl], ni_tot);
     }
-    if (gi.rowptr.empty()) { gi.rowptr = {0}; ig.rowptr = {0}; gg.rowptr = {0}; }
+    if (gi.rowptr.empty()) { gi.rowptr = {0}; ig.rowptr = {0}; gg.rowptr = {0}; ii.rowptr = {0}; }
     A_IG.upload(ig, c->stream); A_GI.upload(gi, c->stream); A_GG.upload(gg, c->stream);
     xcat.alloc(maps.nloc + 1); t1.alloc(maps.nloc + 1); yloc.alloc(maps.nloc + 1);
     rhs.alloc(ni_tot + 1); sol.alloc(ni_tot + 1);
-    stage.ensure(ni_tot);
+    if (ii_ptr) {
+      icg.reset(new InteriorCg);
+      icg->build(c, ii, ioff, ni, reltol);
+    } else {
+      stage.ensure(ni_tot);
+    }
   }
   bool graph_safe() const override { return false; }
   void apply(const double *x, double *y, const int *) override {
@@ -449,22 +552,30 @@ struct MatfreeSchurOp : Operator {
       MI_HIP(hipGetLastError());
       A_IG.launch(0, xcat.p, nullptr, rhs.p, nullptr, s);
       A_GG.launch(0, xcat.p, nullptr, t1.p, nullptr, s);
-      MI_HIP(hipMemcpyAsync(stage.rhs, rhs.p, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
-      MI_HIP(hipStreamSynchronize(s));
-      for (int dl = 0; dl < maps.ndl; ++dl)
-        if (solve(user, d0 + dl, ni[dl], stage.rhs + ioff[dl], stage.sol + ioff[dl]) != 0)
-          raise(MI_ERR_CALLBACK, "interior solve callback failed on subdomain %lld", (long long)(d0 + dl));
-      MI_HIP(hipMemcpyAsync(sol.p, stage.sol, sizeof(double) * ni_tot, hipMemcpyHostToDevice, s));
+      if (icg) {
+        icg->solve(rhs.p, sol.p);
+      } else {
+        MI_HIP(hipMemcpyAsync(stage.rhs, rhs.p, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+        for (int dl = 0; dl < maps.ndl; ++dl)
+          if (solve(user, d0 + dl, ni[dl], stage.rhs + ioff[dl], stage.sol + ioff[dl]) != 0)
+            raise(MI_ERR_CALLBACK, "interior solve callback failed on subdomain %lld", (long long)(d0 + dl));
+        MI_HIP(hipMemcpyAsync(sol.p, stage.sol, sizeof(double) * ni_tot, hipMemcpyHostToDevice, s));
+      }
       A_GI.launch(1, sol.p, t1.p, yloc.p, nullptr, s);
     }
     maps.assemble(ctx, n, yloc.p, y, nullptr);
   }
   void bytes(int64_t *a, int64_t *d) const override {
     *a = A_IG.bytes() + A_GI.bytes() + A_GG.bytes() + 16ll * ni_tot;
-    *d = A_IG.bytes();
+    *d = icg ? icg->A.bytes() : A_IG.bytes();
   }
   void apply_dominant(const double *x) override {
     if (!maps.nloc) return;
+    if (icg) {  // the A_II SpMV of the interior CG (x is not used: the operand is the CG direction buffer)
+      icg->A.launch(0, icg->u.p, nullptr, icg->c.p, nullptr, ctx->stream, icg->u.p, icg->p_uc.p);
+      return;
+    }
     hipLaunchKernelGGL(k_gather, dim3(vec_grid(maps.nloc)), dim3(NT), 0, ctx->stream, maps.nloc, maps.gidx.p, x, xcat.p);
     A_IG.launch(0, xcat.p, nullptr, rhs.p, nullptr, ctx->stream);
   }

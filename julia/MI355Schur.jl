@@ -148,6 +148,25 @@ function MatrixFreeLocalSchurs(ctx::MiContext, A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γ
   wrap(ctx, r, (fref, cb))
 end
 
+"""`MatrixFreeLocalSchurs(ctx, A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γd_Γ2l, node_Γ_cnt; reltol=1e-9)`: the same operator with the
+interior solve on the device — the library's restatement of `IterativeSolvers.cg(A_IIdd[idom], rhs, reltol=reltol)`
+(EPDD.jl:648-650), all local subdomains iterated together."""
+function MatrixFreeLocalSchurs(ctx::MiContext, A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γd_Γ2l, node_Γ_cnt; reltol=1e-9)
+  ndom = length(A_IΓdd); g = flatten_maps(ind_Γd_Γ2l)
+  nd = Int64[length(x) for x in g]; ni = Int64[A.n for A in A_IIdd]
+  iip, iii, iiv = csc_parts(A_IIdd); igp, igi, igv = csc_parts(A_IΓdd); ggp, ggi, ggv = csc_parts(A_ΓΓdd)
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve g iip iii iiv igp igi igv ggp ggi ggv begin
+    check(ccall((:mi_schur_matfree_device_create, lib), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Ptr{Int64}},
+                 Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}},
+                 Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Float64, Cint, Int64, Int64, Ref{Ptr{Cvoid}}),
+                ctx.h, ndom, length(node_Γ_cnt), nd, ni, ptrs(g), ptrs(iip), ptrs(iii), ptrs(iiv),
+                ptrs(igp), ptrs(igi), ptrs(igv), ptrs(ggp), ptrs(ggi), ptrs(ggv), reltol, 1, 0, ndom, r))
+  end
+  wrap(ctx, r)
+end
+
 """`GlobalSchur(ctx, A_IId, A_IΓd, A_ΓΓ, interior)`: `x -> apply_global_schur(A_IId, A_IΓd, A_ΓΓ, x)`
 (EPDD.jl:596-625), the operator of Example03:101."""
 function GlobalSchur(ctx::MiContext, A_IId, A_IΓd, A_ΓΓ::SparseMatrixCSC{Float64,Int}, interior)

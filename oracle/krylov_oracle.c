@@ -291,6 +291,35 @@ orc_op *orc_schur_global_op(i64 ndom, i64 n_gamma, const i64 *n_i,
   return mk_op(gs_apply, c, n_gamma);
 }
 
+/* ------------------------------------------------------------------ interior solve of the matrix-free Schur applies */
+/* `IterativeSolvers.cg(A, b; reltol)` (EPDD.jl:648-650) — third-party (IterativeSolvers.jl, not under
+ * /root/reference; Manifest pins 0.8.5 but the `reltol` keyword needs >= 0.9), restated from its published
+ * CGIterable: x = 0, r = b, u = 0, residual = ||r||, prev = 1, tol = reltol*residual, maxiter = n;
+ * each step: beta = residual^2/prev^2; u = r + beta u; c = A u; alpha = residual^2/(u'c); x += alpha u;
+ * r -= alpha c; prev = residual; residual = ||r||. A symmetric, CSC arrays. Returns the iteration count. */
+i64 orc_interior_cg(i64 n, const i64 *colptr, const i64 *rowval, const double *nzval, const double *b, double *x,
+                    double reltol) {
+  double *r = (double *)malloc(sizeof(double) * (size_t)(3 * n + 3));
+  double *u = r + n, *c = u + n;
+  for (i64 i = 0; i < n; ++i) { x[i] = 0.0; r[i] = b[i]; u[i] = 0.0; }
+  double residual = orc_norm2(n, r), prev = 1.0;
+  const double tol = reltol * residual;
+  i64 it = 0;
+  while (it < n && residual > tol) {
+    const double beta = (residual * residual) / (prev * prev);
+    for (i64 i = 0; i < n; ++i) u[i] = r[i] + beta * u[i];
+    orc_csc_spmv_t(n, n, colptr, rowval, nzval, u, c); /* symmetric: gather form, same per-row order */
+    const double alpha = (residual * residual) / orc_dot(n, u, c);
+    for (i64 i = 0; i < n; ++i) x[i] = x[i] + alpha * u[i];
+    for (i64 i = 0; i < n; ++i) r[i] = r[i] - alpha * c[i];
+    prev = residual;
+    residual = orc_norm2(n, r);
+    ++it;
+  }
+  free(r);
+  return it;
+}
+
 /* ------------------------------------------------------------------ dense `A \ b` (LU, partial pivoting) */
 /* LAPACK dgetf2/dgetrs semantics on a column-major n x n copy. Returns 0, or k+1 if U[k,k]==0
  * (Julia throws SingularException(k+1)). */

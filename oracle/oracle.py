@@ -46,7 +46,7 @@ def lib():
         for name in ("orc_csc_op", "orc_diag_op", "orc_schur_assembled_op", "orc_nn_op",
                      "orc_schur_matfree_op", "orc_schur_global_op"):
             getattr(L, name).restype = C.c_void_p
-        for name in ("orc_cg", "orc_pcg", "orc_defcg", "orc_defpcg"):
+        for name in ("orc_cg", "orc_pcg", "orc_defcg", "orc_defpcg", "orc_interior_cg"):
             getattr(L, name).restype = C.c_int64
         L.orc_op_apply.argtypes = [C.c_void_p, f64p, f64p]
         L.orc_op_free.argtypes = [C.c_void_p]
@@ -239,3 +239,21 @@ def lu_solve(A, b):
     if info:
         raise SingularException(info)
     return b
+
+
+def interior_cg(A: sp.spmatrix, b, reltol: float = 1e-9):
+    """`IterativeSolvers.cg(A_IIdd, b, reltol=reltol)` as the reference's matrix-free applies call it
+    (EPDD.jl:648-650); returns (x, iterations)."""
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    ptr, idx, val = _i64(A.indptr), _i64(A.indices), _f64(A.data)
+    b = _f64(b)
+    x = np.empty(b.size)
+    it = lib().orc_interior_cg(C.c_int64(b.size), _p(ptr, i64p), _p(idx, i64p), _p(val, f64p), _p(b, f64p),
+                               _p(x, f64p), C.c_double(reltol))
+    return x, int(it)
+
+
+def interior_cg_solvers(A_IIdd, reltol: float = 1e-9):
+    """Per-subdomain callables for apply_local_schurs_matfree_operator: the reference's inexact interior solve."""
+    return [lambda rhs, A=A: interior_cg(A, rhs, reltol)[0] for A in A_IIdd]

@@ -345,3 +345,34 @@ def test_folded_unfolded_and_eager_loops_agree(pkg, ctx, orc, fem):
     for it, res in outs:
         assert it == int(G["pcg_it"])
         assert np.allclose(res, G["pcg_res_norm"], rtol=RES_RTOL, atol=RES_FLOOR * res[0])
+
+
+# ------------------------------------------------------------------ matrix-free operator with the interior CG on the device
+def test_matrix_free_device_interior_cg(pkg, ctx, orc, ragged):
+    """`apply_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, ...; reltol)` with `IterativeSolvers.cg` as the interior solve
+    (EPDD.jl:648-650): the device CG (batched over subdomains) against the oracle's restatement of the same iteration,
+    and against the exact (direct interior solve) operator within the interior tolerance."""
+    api = pkg.api
+    P = ragged
+    n = P.sub.n_Γ
+    rng = np.random.default_rng(21)
+    v = rng.standard_normal(n)
+    for reltol in (1e-9, 1e-5):
+        Sd = api.MatrixFreeLocalSchurs(ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, P.sub.node_Γ_cnt, None, reltol=reltol)
+        So = orc.apply_local_schurs_matfree_operator(P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, n,
+                                                     orc.interior_cg_solvers(P.A_IIdd, reltol))
+        got, want = Sd * v, So * v
+        # Same iteration, different summation order inside the dots. Both are inexact solves that stop at
+        # ||r|| <= reltol*||rhs||, so they agree to the order of that tolerance, not to rounding (measured:
+        # 0.05*reltol between them, 0.07*reltol from the exact operator).
+        assert np.allclose(got, want, rtol=0, atol=0.5 * reltol * np.abs(want).max())
+    Sx = api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+    Sdev = api.MatrixFreeLocalSchurs(ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, P.sub.node_Γ_cnt, None)
+    exact = Sx * v
+    assert np.allclose(Sdev * v, exact, rtol=0, atol=1e-7 * np.abs(exact).max())       # Example03:175 with inexact solves
+    assert not np.any(Sdev * np.zeros(n))                                                # rhs = 0: zero iterations
+    # NN-PCG on the inexact operator converges like on the exact one (Example03 runs exactly this with S_local)
+    M = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+    x, it, res = api.pcg(Sdev, P.b_schur, np.zeros(n), M)
+    xe, ite, rese = api.pcg(Sx, P.b_schur, np.zeros(n), M)
+    assert abs(it - ite) <= 1 and np.linalg.norm(x - xe) <= 1e-5 * np.linalg.norm(xe)

@@ -281,3 +281,24 @@ def test_reference_npz_round_trip(pkg, fem, tmp_path):
     assert np.allclose(spectrum(P1), spectrum(P3), rtol=1e-9)
     path = io.save_pcg_iters([15, 16, 15], "DoF576", 4, "0", 3, d)
     assert np.array_equal(np.load(path), [15, 16, 15])
+
+
+def test_interior_cg_restates_iterative_solvers(orc, micro):
+    """`IterativeSolvers.cg(A_IIdd, rhs, reltol=1e-9)` — the reference's interior solve (EPDD.jl:648-650): converges to
+    the stated relative residual from x = 0, and the matrix-free operator built on it agrees with the exact operator to
+    that tolerance (what Example03:175 prints with its inexact solves)."""
+    P = micro
+    A = P.A_IIdd[0]
+    b = np.random.default_rng(4).standard_normal(A.shape[0])
+    for reltol in (1e-9, 1e-4):
+        x, it = orc.interior_cg(A, b, reltol)
+        assert 0 < it <= A.shape[0]
+        assert np.linalg.norm(b - A @ x) <= 1.5 * reltol * np.linalg.norm(b)
+    x0, it0 = orc.interior_cg(A, np.zeros(A.shape[0]))
+    assert it0 == 0 and not np.any(x0)
+    n = P.sub.n_Γ
+    Se = orc.apply_local_schurs_operator(P.Sd, P.sub.gather_idx, n)
+    Si = orc.apply_local_schurs_matfree_operator(P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, n,
+                                                 orc.interior_cg_solvers(P.A_IIdd, 1e-9))
+    v = P.b_schur
+    assert np.allclose(Si(v), Se(v), rtol=0, atol=1e-7 * np.abs(Se(v)).max())

@@ -56,3 +56,14 @@ t0 = time.perf_counter(); Sm * b; t1 = time.perf_counter()
 print(f"matrix-free S-apply : {(t1 - t0) * 1e3:8.1f} ms (8 host interior solves of ~124k unknowns + PCIe + 3 SpMV launches)")
 t0 = time.perf_counter(); x, it, res = api.pcg(Sm, b, np.zeros(n), M); t1 = time.perf_counter()
 print(f"matrix-free pcg     : it={it} {(t1 - t0):8.2f} s/solve {(it - 1) / (t1 - t0):9.2f} it/s")
+Sg = api.MatrixFreeLocalSchurs(ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, P.sub.node_Γ_cnt, None, reltol=1e-9)
+Sg * b
+t0 = time.perf_counter(); yg = Sg * b; t1 = time.perf_counter()
+ya = S * b
+print(f"matrix-free S-apply, interior CG on the device (reltol 1e-9): {(t1 - t0) * 1e3:8.1f} ms; "
+      f"|Δ| vs assembled = {np.abs(yg - ya).max() / np.abs(ya).max():.2e}")
+_, nb = Sg.bytes()
+us = Sg.time_dominant(bd, 100)
+print(f"A_II SpMV (block-diagonal, {nb / 1e6:.1f} MB algorithmic): {us:7.2f} us/launch {nb / us / 1e3:8.1f} GB/s")
+t0 = time.perf_counter(); x, it, res = api.pcg(Sg, b, np.zeros(n), M); t1 = time.perf_counter()
+print(f"matrix-free pcg, device interior CG: it={it} {(t1 - t0):8.2f} s/solve {(it - 1) / (t1 - t0):9.2f} it/s")

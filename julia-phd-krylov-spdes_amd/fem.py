@@ -444,6 +444,30 @@ class InteriorSolver:
         return self.lu.solve(np.ascontiguousarray(rhs, dtype=np.float64))
 
 
+class LazySolvers:
+    """`solvers[d]`: the InteriorSolver of subdomain d, factorised on first use (d outside [lo, hi) -> None)."""
+
+    def __init__(self, A_II, lo, hi):
+        self._A, self._lo, self._hi, self._f = A_II, lo, hi, {}
+
+    def __len__(self):
+        return len(self._A)
+
+    def __getitem__(self, d):
+        if isinstance(d, slice):
+            return [self[k] for k in range(*d.indices(len(self)))]
+        if d < 0:
+            d += len(self._A)
+        if not (self._lo <= d < self._hi):
+            return None
+        if d not in self._f:
+            self._f[d] = InteriorSolver(self._A[d])
+        return self._f[d]
+
+    def __iter__(self):
+        return (self[d] for d in range(len(self._A)))
+
+
 def _bfs_levels_from_interface(A_II: sp.csr_matrix, seeds: np.ndarray):
     """Breadth-first levels of the graph of A_II starting from `seeds`; nodes that are not
     connected to the seeds are left out (they cannot influence the Schur complement)."""
@@ -479,30 +503,36 @@ def _dense_device():
     return torch, torch.device("cpu")
 
 
-def local_schur_by_level_elimination(A_II, A_IΓ, A_ΓΓ) -> np.ndarray:
-    """Dense S_d = A_ΓΓ - A_IΓ' A_II^{-1} A_IΓ by exact block elimination.
+def local_schur_by_level_elimination(A_II, A_IΓ, A_ΓΓ, b_I=None):
+    """Dense S_d = A_ΓΓ - A_IΓ' A_II^{-1} A_IΓ by exact block elimination; with `b_I` also the condensed
+    right-hand side A_IΓ' A_II^{-1} b_I (what `get_schur_rhs` subtracts from b_Γ, EPDD.jl:853-861), returned as
+    (S_d, w_d).
 
     The interior is split into breadth-first levels L_0, L_1, ... grown from the interior nodes
     adjacent to Γ_d; A_II is block tridiagonal in that ordering, so eliminating from the deepest
-    level towards Γ_d is the recursion T_m = A_mm, T_k = A_kk - A_{k+1,k}' T_{k+1}^{-1} A_{k+1,k},
-    and S_d = A_ΓΓ - A_{0Γ}' T_0^{-1} A_{0Γ}. Every step is dense Cholesky + triangular solve +
-    product (BLAS-3), which is far faster than n_Γd sparse triangular solves with 124 k unknowns.
+    level towards Γ_d is the recursion T_m = A_mm, T_k = A_kk - A_{k+1,k}' T_{k+1}^{-1} A_{k+1,k}
+    (and g_m = b_m, g_k = b_k - A_{k+1,k}' T_{k+1}^{-1} g_{k+1}), and S_d = A_ΓΓ - A_{0Γ}' T_0^{-1} A_{0Γ},
+    w_d = A_{0Γ}' T_0^{-1} g_0. Every step is dense Cholesky + triangular solve + product (BLAS-3), which is
+    far faster than n_Γd sparse triangular solves with 124 k unknowns. Interior nodes not connected to Γ_d
+    cannot influence either result and are left out.
     """
     A_II = sp.csr_matrix(A_II)
     A_IΓ = sp.csr_matrix(A_IΓ)
     S = np.asarray(sp.csr_matrix(A_ΓΓ).todense(), dtype=np.float64)
     seeds = np.flatnonzero(np.diff(A_IΓ.indptr) > 0)
     if seeds.size == 0:
-        return S
+        return S if b_I is None else (S, np.zeros(S.shape[0]))
     levels = _bfs_levels_from_interface(A_II, seeds)
     perm = np.concatenate(levels)
     off = np.concatenate(([0], np.cumsum([l.size for l in levels])))
     Ap = sp.csr_matrix(A_II[perm][:, perm])
     torch, dev = _dense_device()
 
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev) if torch is not None else a
+
     def blk(i, j):
-        a = Ap[off[i]:off[i + 1], off[j]:off[j + 1]].toarray()
-        return torch.from_numpy(a).to(dev) if torch is not None else a
+        return to_dev(Ap[off[i]:off[i + 1], off[j]:off[j + 1]].toarray())
 
     if torch is not None:
         chol = torch.linalg.cholesky
@@ -514,33 +544,49 @@ def local_schur_by_level_elimination(A_II, A_IΓ, A_ΓΓ) -> np.ndarray:
         def trsm(c, b):
             return sla.solve_triangular(c, b, lower=True, check_finite=False)
 
+    bp = None if b_I is None else np.asarray(b_I, dtype=np.float64)[perm]
     m = len(levels) - 1
     T = blk(m, m)
+    g = None if bp is None else to_dev(bp[off[m]:off[m + 1]].reshape(-1, 1))
     for k in range(m - 1, -1, -1):
-        Y = trsm(chol(T), blk(k + 1, k))
-        T = blk(k, k) - Y.T @ Y
-    B = A_IΓ[levels[0]].toarray()
-    Y = trsm(chol(T), torch.from_numpy(B).to(dev) if torch is not None else B)
-    YtY = Y.T @ Y
+        c = chol(T)
+        C = blk(k + 1, k)
+        Y = trsm(c, C if g is None else (torch.cat([C, g], 1) if torch is not None else np.hstack([C, g])))
+        Yc = Y if g is None else Y[:, :-1]
+        T = blk(k, k) - Yc.T @ Yc
+        if g is not None:
+            g = to_dev(bp[off[k]:off[k + 1]].reshape(-1, 1)) - Yc.T @ Y[:, -1:]
+    c = chol(T)
+    B = to_dev(A_IΓ[levels[0]].toarray())
+    Y = trsm(c, B if g is None else (torch.cat([B, g], 1) if torch is not None else np.hstack([B, g])))
+    Yc = Y if g is None else Y[:, :-1]
+    YtY = Yc.T @ Yc
     S -= YtY.cpu().numpy() if torch is not None else YtY
-    return S
+    if g is None:
+        return S
+    w = Yc.T @ Y[:, -1:]
+    return S, (w.cpu().numpy() if torch is not None else w).ravel()
 
 
 def assemble_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, solvers: Optional[Sequence["InteriorSolver"]] = None,
-                          method: str = "levels", chunk: int = 256):
+                          method: str = "levels", chunk: int = 256, b_Id=None):
     """`assemble_local_schurs` (EPDD.jl:667-695): dense S_d = A_ΓΓd - A_IΓd' A_IId^{-1} A_IΓd.
 
     The reference applies `apply_local_schur` (interior CG, reltol 1e-9) to every unit vector and
     keeps the upper triangle (`Symmetric(Array(map))`, :692). Here the blocks come from an exact
     direct elimination (`method="levels"`, see local_schur_by_level_elimination) or from multi-RHS
     SuperLU solves (`method="solves"`, slow; kept as the cross-check), and are symmetrised the
-    same way. Returns column-major (Fortran-order) arrays like Julia's `Array`.
+    same way. Returns column-major (Fortran-order) arrays like Julia's `Array`; with `b_Id` (levels only)
+    also the list of condensed right-hand sides A_IΓd' A_IId^{-1} b_Id.
     """
-    out = []
+    out, ws = [], []
     for d in range(len(A_IIdd)):
         n = A_ΓΓdd[d].shape[0]
         if method == "levels":
-            S = local_schur_by_level_elimination(A_IIdd[d], A_IΓdd[d], A_ΓΓdd[d])
+            res = local_schur_by_level_elimination(A_IIdd[d], A_IΓdd[d], A_ΓΓdd[d], None if b_Id is None else b_Id[d])
+            S = res if b_Id is None else res[0]
+            if b_Id is not None:
+                ws.append(res[1])
         else:
             solve = solvers[d] if solvers is not None else InteriorSolver(A_IIdd[d])
             S = np.asarray(A_ΓΓdd[d].todense(), dtype=np.float64)
@@ -552,14 +598,24 @@ def assemble_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, solvers: Optional[Sequence[
                 S[:, c0:c1] -= AΓI @ V
         S = np.triu(S) + np.triu(S, 1).T
         out.append(np.asfortranarray(S))
-    return out
+    return out if b_Id is None else (out, ws)
 
 
 def prepare_neumann_neumann_schur_precond(Sd: Sequence[np.ndarray]):
     """`prepare_neumann_neumann_schur_precond(Sd_local_mat, ...)` (EPDD.jl:1201-1220):
-    ΠS_d = pinv(S_d, rtol = sqrt(eps(Float64)))."""
+    ΠS_d = pinv(S_d, rtol = sqrt(eps(Float64))) — SVD-based, singular values <= rtol*σ_max dropped.
+    Runs on the GPU through torch when one is visible (set-up only), else numpy; same definition."""
     rtol = float(np.sqrt(np.finfo(np.float64).eps))
-    return [np.asfortranarray(np.linalg.pinv(np.asarray(S), rcond=rtol)) for S in Sd]
+    torch, dev = _dense_device()
+    out = []
+    for S in Sd:
+        S = np.asarray(S, dtype=np.float64)
+        if torch is not None and dev.type == "cuda" and S.shape[0] > 0:
+            P = torch.linalg.pinv(torch.from_numpy(np.ascontiguousarray(S)).to(dev), rtol=rtol, hermitian=False).cpu().numpy()
+        else:
+            P = np.linalg.pinv(S, rcond=rtol)
+        out.append(np.asfortranarray(P))
+    return out
 
 
 def get_schur_rhs(b_Id, A_IId, A_IΓd, b_Γ, gather_idx=None, solvers=None):
@@ -669,18 +725,25 @@ def build_schur_problem(N: int, px: int, py: int, coeff: Coeff, f, uexact,
     sub = set_subdomains(mesh.cells, mesh.cell_neighbors, epart, npart, dinds.dirichlet_g2l)
     A_II, A_IΓ, A_ΓΓ, b_Id, b_Γ = prepare_local_schurs(mesh.cells, mesh.points, epart, sub, coeff, f, uexact)
     lo, hi = (0, sub.ndom) if dom_slice is None else dom_slice
-    solvers = [InteriorSolver(A_II[d]) if lo <= d < hi else None for d in range(sub.ndom)]
+    loc = range(lo, hi)
     b_schur = np.array(b_Γ, copy=True) if lo == 0 else np.zeros_like(b_Γ)
-    for d in range(lo, hi):                 # get_schur_rhs (EPDD.jl:835-864), this rank's subdomains
-        b_schur[sub.gather_idx[d]] -= A_IΓ[d].T @ solvers[d](b_Id[d])
+    solvers = LazySolvers(A_II, lo, hi)          # SuperLU factors, built only if something asks for them
+    Sd = Pi = None
+    if assemble:
+        # one elimination per subdomain gives S_d and the condensed rhs (get_schur_rhs, EPDD.jl:835-864)
+        Sl, wl = assemble_local_schurs([A_II[d] for d in loc], [A_IΓ[d] for d in loc], [A_ΓΓ[d] for d in loc],
+                                       b_Id=[b_Id[d] for d in loc])
+        for d in loc:
+            b_schur[sub.gather_idx[d]] -= wl[d - lo]
+        Sd = [Sl[d - lo] if lo <= d < hi else None for d in range(sub.ndom)]
+        if precond:
+            Pl = prepare_neumann_neumann_schur_precond(Sl)
+            Pi = [Pl[d - lo] if lo <= d < hi else None for d in range(sub.ndom)]
+    else:
+        for d in loc:                           # get_schur_rhs with sparse direct interior solves
+            b_schur[sub.gather_idx[d]] -= A_IΓ[d].T @ solvers[d](b_Id[d])
     prob = SchurProblem(mesh, dinds, sub, epart, A_II, A_IΓ, A_ΓΓ, b_Id, b_Γ, b_schur,
                         solvers=solvers, uexact=uexact)
     prob.info["dom_slice"] = (lo, hi)
-    if assemble:
-        loc = range(lo, hi)
-        Sd = assemble_local_schurs([A_II[d] for d in loc], [A_IΓ[d] for d in loc], [A_ΓΓ[d] for d in loc])
-        prob.Sd = [Sd[d - lo] if lo <= d < hi else None for d in range(sub.ndom)]
-        if precond:
-            Pi = prepare_neumann_neumann_schur_precond(Sd)
-            prob.ΠSd = [Pi[d - lo] if lo <= d < hi else None for d in range(sub.ndom)]
+    prob.Sd, prob.ΠSd = Sd, Pi
     return prob

@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=-1, help="iterations per captured graph (-1: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=200)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-GPU code path (process group, RCCL communicator, all-reduces) even with one rank")
     ap.add_argument("--workload", choices=["schur", "fullA"], default="schur",
                     help="schur: configs[2] (headline, default). fullA: configs[1], pcg on the full matrix (CSR SpMV + BLAS-1)")
     ap.add_argument("--eps", type=float, default=1e-7, help="stop tolerance (reference constant 1e-7; other values for analysis only)")
@@ -134,7 +136,8 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = graft.load_package()
@@ -159,7 +162,7 @@ def main():
     ctx = api.Context(local_rank)
     if args.chunk >= 0:
         ctx.set_chunk(args.chunk)
-    if world > 1:
+    if multi:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid = torch.frombuffer(bytearray(ctx.unique_id()), dtype=torch.uint8).cuda()
@@ -179,7 +182,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         ctx.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
 
     # ---------------- warm-up, then the timed region: EXACTLY K solves
@@ -197,7 +200,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert it == its, "iteration count changed between solves"
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -230,7 +233,7 @@ def main():
         return float(np.median(ts))
 
     short = max(2, min(5, its - 2))
-    folded = world == 1 and its > short + 2
+    folded = not multi and its > short + 2
     k_us = None
     if folded:
         t_short = gpu_ms(short)
@@ -241,19 +244,24 @@ def main():
     M.apply_dominant(b_dev, reps=20)
     k_ms = kernel_us(api, ctx, S, b_dev, args.kernel_reps) * 1e-3
     nn_ms = kernel_us(api, ctx, M, b_dev, args.kernel_reps) * 1e-3
-    traffic = None
+    pmc_table = {}
     pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/hbm_traffic.py from rocprofv3 --pmc passes
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("dominant_kernel_bytes_per_launch")
+            pmc_table = json.load(open(pmc))
         except Exception:
-            traffic = None
+            pmc_table = {}
     bytes_launch = (bytes_dom + bytes_nn) / 2
     if k_us is None:               # N>1: the unfolded launches run; report the plain S-apply GEMV
         k_us, kname = k_ms * 1e3, "k_gemv_batched<S-apply>"
         bytes_launch = bytes_dom
     else:
         kname = "k_gemv_pcg (S-apply / NN-apply GEMV with the PCG update folded in; average of both phases)"
+    if kname.startswith("k_gemv_pcg"):
+        traffic = pmc_table.get("dominant_kernel_bytes_per_launch")
+    else:
+        traffic = next((v["bytes_per_launch"] for k, v in pmc_table.items()
+                        if isinstance(v, dict) and "k_gemv_batched" in k and "false" in k), None)
     achieved = bytes_launch / (k_us * 1e-6) / 1e9
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -297,7 +305,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

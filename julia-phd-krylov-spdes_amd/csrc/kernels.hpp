@@ -925,6 +925,59 @@ __global__ __launch_bounds__(NTF) void k_fused_p(int n, SolverState *st, AsmView
     st->done = !((it < maxit) && (res > tol));
   }
 }
+// Unpreconditioned cg (cg.jl:35-47): both halves of the iteration in ONE single-workgroup launch — z is r,
+// so nothing but two workgroup reductions separates alpha from beta:
+//   d = p'Ap; alpha = r'r/d; x += alpha p; r -= alpha Ap; r'r; beta = (1/old)*new; p = beta p + r; it; stop rule.
+template <int EPT>
+__global__ __launch_bounds__(NTF) void k_fused_cg(int n, SolverState *st, AsmView vAp, double *__restrict__ p,
+                                                  double *__restrict__ x, double *__restrict__ r, double *res_norm) {
+  if (st->done) return;
+  __shared__ double sm[NTF / 64 + 1];
+  const double rTr0 = st->rTr, tol = st->tol;
+  const long long it0 = st->it, maxit = st->maxit, cap = st->res_cap;
+  double pe[EPT], ae[EPT], xe[EPT], re[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = k * NTF + threadIdx.x;
+    pe[k] = ae[k] = xe[k] = re[k] = 0.0;
+    if (e < n) { ae[k] = view_load(vAp, e); pe[k] = p[e]; xe[k] = x[e]; re[k] = r[e]; }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) s += pe[k] * ae[k];
+  const double d = block_sum_f(s, sm);
+  const double alpha = rTr0 / d;
+  double srr = 0.0;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = k * NTF + threadIdx.x;
+    if (e < n) {
+      x[e] = xe[k] + alpha * pe[k];
+      re[k] = re[k] + (-alpha) * ae[k];
+      r[e] = re[k];
+      srr += re[k] * re[k];
+    }
+  }
+  const double rr = block_sum_f(srr, sm);
+  double beta = 1. / rTr0;
+  beta *= rr;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = k * NTF + threadIdx.x;
+    if (e < n) p[e] = beta * pe[k] + re[k];
+  }
+  if (threadIdx.x == 0) {
+    st->d = d; st->alpha = alpha; st->beta = beta;
+    st->rTr_prev = rTr0; st->rTz_prev = rTr0;
+    st->rTr = rr; st->rTz = rr;
+    const long long it = it0 + 1;
+    st->it = it;
+    const double res = sqrt(rr);
+    if (it <= cap) res_norm[it - 1] = res; else st->overflow = 1;
+    st->done = !((it < maxit) && (res > tol));
+  }
+}
+
 // Set-up, first half: r = b - A*x (Ap as a view); r'r and b'b   (cg.jl:28-29,32 / 83-84,88).
 // FOLD: also the scalars the folded PCG launches (k_gemv_pcg) expect at start-up: tol, it_nxt = 0,
 // rTz_prev = 1, flags cleared (the first PHASE 1 launch gathers r_0 and treats p as 0 by itself).

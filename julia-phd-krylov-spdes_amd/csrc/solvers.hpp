@@ -212,6 +212,13 @@ struct Krylov {
     if (fused) {
       // small Γ systems: 4 launches per iteration (GEMV, fused, GEMV, fused)
       const AsmView vAp = A->apply_view(ws.p, ws.Ap, dn);             // mul!(Ap, A, p), Γ-sum deferred
+      if (!pre && nvec == 0) {                                        // cg: 2 launches per iteration
+#define MI_CALL(E) hipLaunchKernelGGL((k_fused_cg<E>), dim3(1), dim3(NTF), 0, s, n, ws.st, vAp, ws.p, ws.x, ws.r, ws.res_norm.p)
+        MI_EPT_DISPATCH(MI_CALL);
+#undef MI_CALL
+        MI_HIP(hipGetLastError());
+        return;
+      }
 #define MI_CALL(E) hipLaunchKernelGGL((k_fused_xr<E>), dim3(1), dim3(NTF), 0, s, n, ws.st, vAp, ws.p, ws.x, ws.r, pre)
       MI_EPT_DISPATCH(MI_CALL);                                       // alpha; x += alpha p; r -= alpha Ap; r'r
 #undef MI_CALL
@@ -373,8 +380,12 @@ struct Krylov {
     if (use_graph) {
       const GraphKey pk{A, M, nvec, 0};
       int &predicted = ws.predicted[pk];
-      const int64_t first = std::max<int64_t>(1, std::min<int64_t>(predicted > 0 ? predicted : ctx->chunk,
-                                                                  std::min<int64_t>(maxit, 1024)));
+      // Exact prediction for short solves; long ones (hundreds of iterations, counts that drift from solve to
+      // solve) round down to a multiple of 32 so that only a few graph sizes are ever instantiated.
+      int64_t first = predicted > 0 ? predicted : ctx->chunk;
+      if (first > 64) first -= first % 32;
+      first = std::max<int64_t>(1, std::min<int64_t>(first, std::min<int64_t>(maxit, 1024)));
+      if (ws.graphs.size() > 48) ws.drop_graphs();
       hipGraphExec_t g0 = nullptr;
       try {
         g0 = graph(-(int)first);

@@ -874,15 +874,39 @@ __global__ __launch_bounds__(NTF) void k_fused_xr(int n, SolverState *st, AsmVie
     st->rTr = srr;
   }
 }
+// mu = WtAW \ rhs by ONE wave, in registers: lane i holds b[i]; row swaps, unit-lower forward and upper backward
+// substitution in the order of LAPACK getrs (and of k_lu_solve), values exchanged with wave shuffles. nvec <= 64.
+__device__ __forceinline__ double wave_lu_solve(int nvec, const double *__restrict__ LU, const int *__restrict__ piv,
+                                                double b) {
+  const int lane = threadIdx.x & 63;
+  for (int k = 0; k < nvec; ++k) {
+    const int pk = piv[k];
+    const double vk = __shfl(b, k, 64), vp = __shfl(b, pk, 64);
+    if (pk != k) { if (lane == k) b = vp; else if (lane == pk) b = vk; }
+  }
+  for (int k = 0; k < nvec; ++k) {
+    const double bk = __shfl(b, k, 64);
+    if (lane > k && lane < nvec) b -= bk * LU[lane + (long long)k * nvec];
+  }
+  for (int k = nvec - 1; k >= 0; --k) {
+    if (lane == k) b /= LU[k + (long long)k * nvec];
+    const double bk = __shfl(b, k, 64);
+    if (lane < k) b -= bk * LU[lane + (long long)k * nvec];
+  }
+  return b;
+}
 // z = view; r'z; beta = (1/old)*new; p = beta p + z [- W mu]; it += 1; res_norm[it]; stop rule
-// (cg.jl:44-47 / 100-106; defcg.jl:76-80 / 299-305). r'r was stored by k_fused_xr.
+// (cg.jl:44-47 / 100-106; defcg.jl:76-80 / 299-305). r'r was stored by k_fused_xr. Deflation: mu is either
+// given, or (LU != nullptr, nvec <= 64) solved here from rhs[v] = WtA[v,:].z by the first wave.
 template <int EPT>
 __global__ __launch_bounds__(NTF) void k_fused_p(int n, SolverState *st, AsmView vz, const double *__restrict__ r,
                                                  double *__restrict__ p, const double *__restrict__ W,
                                                  const double *__restrict__ mu, int nvec, double *res_norm,
-                                                 int precond) {
+                                                 int precond, const double *__restrict__ LU,
+                                                 const int *__restrict__ piv, const double *__restrict__ rhs) {
   if (st->done) return;  // written only by thread 0 at the very end, behind the barriers below
   __shared__ double sm[NTF / 64 + 1];
+  __shared__ double mu_s[64];
   const double rr = st->rTr;
   const double old = precond ? st->rTz_prev : st->rTr_prev;
   const double tol = st->tol;
@@ -899,7 +923,12 @@ __global__ __launch_bounds__(NTF) void k_fused_p(int n, SolverState *st, AsmView
       if (precond) s += r[e] * ze[k];
     }
   }
+  if (nvec > 0 && LU && threadIdx.x < 64) {
+    const double m = wave_lu_solve(nvec, LU, piv, threadIdx.x < (unsigned)nvec ? rhs[threadIdx.x] : 0.0);
+    mu_s[threadIdx.x] = m;
+  }
   const double rz = precond ? block_sum_f(s, sm) : rr;
+  if (!precond) __syncthreads();  // mu_s visible (block_sum_f has barriers of its own)
   double beta = 1. / old;
   beta *= rz;
 #pragma unroll
@@ -909,7 +938,7 @@ __global__ __launch_bounds__(NTF) void k_fused_p(int n, SolverState *st, AsmView
       double v = beta * pe[k] + ze[k];
       if (nvec > 0) {
         double wm = 0.0;
-        for (int q = 0; q < nvec; ++q) wm += W[(long long)q * n + e] * mu[q];
+        for (int q = 0; q < nvec; ++q) wm += W[(long long)q * n + e] * (LU ? mu_s[q] : mu[q]);
         v = v - wm;
       }
       p[e] = v;
@@ -1076,6 +1105,17 @@ __global__ __launch_bounds__(NT) void k_multi_dot_partial(int n, const double *_
   for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) s += v[i] * z[i];
   s = block_sum(s, sm);
   if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+// part[v] = V[:,v] . z with z given as a view (small systems: one workgroup per vector); grid (nvec)
+__global__ __launch_bounds__(NT) void k_multi_dot_view(int n, const double *__restrict__ V, AsmView vz,
+                                                       double *__restrict__ part, const int *done) {
+  if (done && *done) return;
+  __shared__ double sm[NT / 64 + 1];
+  const double *v = V + (long long)blockIdx.x * n;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += NT) s += v[i] * view_load(vz, i);
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 // C[i + j*nvec] = partial-free small gemm entry AW[:,i] . W[:,j]; grid (nvec, nvec), one workgroup each.
 __global__ __launch_bounds__(NT) void k_small_gram(int n, const double *__restrict__ AW, const double *__restrict__ W,

@@ -223,13 +223,21 @@ struct Krylov {
       MI_EPT_DISPATCH(MI_CALL);                                       // alpha; x += alpha p; r -= alpha Ap; r'r
 #undef MI_CALL
       AsmView vz{ws.r, 0};
-      if (pre) {
-        if (nvec > 0) { M->apply(ws.r, ws.z, dn); vz = AsmView{ws.z, 0}; }  // WtA*z needs z itself
-        else vz = M->apply_view(ws.r, ws.z, dn);                     // z .= M \ r, Γ-sum deferred
+      if (pre) vz = M->apply_view(ws.r, ws.z, dn);                    // z .= M \ r, Γ-sum deferred
+      const bool wave_lu = nvec > 0 && nvec <= 64;                    // mu solved inside k_fused_p by one wave
+      if (wave_lu) {
+        hipLaunchKernelGGL(k_multi_dot_view, dim3(nvec), dim3(NT), 0, s, n, ws.AW.p, vz, ws.part_mu.p, dn);  // WtA * z
+      } else if (nvec > 0) {
+        if (vz.width) {  // materialise z for the generic projection kernels
+          hipLaunchKernelGGL(k_assemble_slots, dim3(vec_grid(n)), dim3(NT), 0, s, n, vz.width, vz.src, ws.z, dn);
+          vz = AsmView{ws.z, 0};
+        }
+        project(ws.AW.p, vz.src, dn);                                 // mu .= WtAW \ (WtA * z)
       }
-      if (nvec > 0) project(ws.AW.p, vz.src, dn);                     // mu .= WtAW \ (WtA * z)
-#define MI_CALL(E) hipLaunchKernelGGL((k_fused_p<E>), dim3(1), dim3(NTF), 0, s, n, ws.st, vz, ws.r, ws.p, Wp, mup, nvec, ws.res_norm.p, pre)
-      MI_EPT_DISPATCH(MI_CALL);                                       // beta; p; it += 1; res_norm[it]; stop rule
+      const double *lup = wave_lu ? ws.LU.p : nullptr;
+      const int *pivp = wave_lu ? ws.piv.p : nullptr;
+#define MI_CALL(E) hipLaunchKernelGGL((k_fused_p<E>), dim3(1), dim3(NTF), 0, s, n, ws.st, vz, ws.r, ws.p, Wp, mup, nvec, ws.res_norm.p, pre, lup, pivp, ws.part_mu.p)
+      MI_EPT_DISPATCH(MI_CALL);                                       // beta; [mu;] p; it += 1; res_norm[it]; stop rule
 #undef MI_CALL
       MI_HIP(hipGetLastError());
       return;

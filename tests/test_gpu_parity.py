@@ -376,3 +376,18 @@ def test_matrix_free_device_interior_cg(pkg, ctx, orc, ragged):
     x, it, res = api.pcg(Sdev, P.b_schur, np.zeros(n), M)
     xe, ite, rese = api.pcg(Sx, P.b_schur, np.zeros(n), M)
     assert abs(it - ite) <= 1 and np.linalg.norm(x - xe) <= 1e-5 * np.linalg.norm(xe)
+
+
+def test_deflation_with_many_vectors(pkg, ctx, orc, toy):
+    """nvec > 64 takes the generic projection kernels (k_multi_dot_partial + k_lu_solve) instead of the one-wave
+    solve inside the fused p-update; nvec = 1 and nvec = 64 sit on the edges of the in-kernel path."""
+    api = pkg.api
+    P = toy
+    S, M = gpu_ops(pkg, ctx, P)
+    So, Mo = orc_ops(orc, P)
+    n, b = P.sub.n_Γ, P.b_schur
+    Q = np.linalg.qr(np.random.default_rng(17).standard_normal((n, 70)))[0]
+    for nvec in (1, 64, 70):
+        W = np.asfortranarray(Q[:, :nvec])
+        assert_history(api.defpcg(S, b, np.zeros(n), W, M), orc.defpcg(So, b, np.zeros(n), W, Mo))
+        assert_history(api.defcg(S, b, np.zeros(n), W), orc.defcg(So, b, np.zeros(n), W), So, b)

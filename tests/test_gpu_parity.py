@@ -27,27 +27,29 @@ TIGHT_PREFIX = 20
 
 
 def assert_history(got, want, apply=None, b=None):
-    """`it` equal; res_norm within RES_RTOL (+floor) on the first TIGHT_PREFIX entries — every
-    entry when the solve is that short, which covers all preconditioned cases. Beyond that, CG in
-    finite precision amplifies summation-order differences (the oracle sums left to right, the GPU
-    in lane-strided trees), so later entries of long unpreconditioned runs are only required to
-    stay within a factor 2, and the answer is checked independently through the true residual
-    ||b - A x|| computed with the oracle's operator (`apply`)."""
+    """Short solves (it <= TIGHT_PREFIX, i.e. every well-preconditioned case incl. the 1M-DoF headline): `it`
+    EQUAL and every res_norm entry within RES_RTOL (+floor).
+    Long solves: CG in finite precision amplifies summation-order differences (the oracle sums left to right,
+    the GPU in lane-strided trees) — between any two BLAS builds as well. There the first TIGHT_PREFIX entries
+    are still held to RES_RTOL, later entries of the common part to a factor 2, `it` to +-max(1, 2 %), and the
+    answer is checked independently through the true residual ||b - A x|| with the oracle's operator."""
     x, it, res = got
     xo, ito, reso = want
-    assert it == ito, f"iteration counts differ: {it} vs oracle {ito}"
-    assert res.shape == reso.shape
-    k = min(TIGHT_PREFIX, it)
+    if max(it, ito) <= TIGHT_PREFIX:
+        assert it == ito, f"iteration counts differ: {it} vs oracle {ito}"
+        assert np.allclose(res, reso, rtol=RES_RTOL, atol=RES_FLOOR * reso[0]), np.max(np.abs(res - reso) / reso)
+        assert np.linalg.norm(x - xo) <= X_RTOL * np.linalg.norm(xo)
+        return
+    assert abs(it - ito) <= max(1, ito // 50), f"iteration counts differ: {it} vs oracle {ito}"
+    k, m = TIGHT_PREFIX, min(it, ito)
     assert np.allclose(res[:k], reso[:k], rtol=RES_RTOL, atol=RES_FLOOR * reso[0]), \
         np.max(np.abs(res[:k] - reso[:k]) / reso[:k])
-    if it > k:
-        ratio = res[k:] / reso[k:]
-        assert ratio.max() < 2.0 and ratio.min() > 0.5, (ratio.min(), ratio.max())
-        assert apply is not None and b is not None, "long runs need the true-residual check"
-        assert np.linalg.norm(b - apply(x)) <= 2.0 * max(res[-1], 1e-7 * np.linalg.norm(b))
-        assert np.linalg.norm(x - xo) <= 1e-4 * np.linalg.norm(xo)
-    else:
-        assert np.linalg.norm(x - xo) <= X_RTOL * np.linalg.norm(xo)
+    ratio = res[k:m] / reso[k:m]
+    assert ratio.size == 0 or (ratio.max() < 2.0 and ratio.min() > 0.5), (ratio.min(), ratio.max())
+    assert apply is not None and b is not None, "long runs need the true-residual check"
+    bn = np.linalg.norm(b)
+    assert np.linalg.norm(b - apply(x)) <= 2.0 * max(res[-1], 1e-7 * bn)
+    assert np.linalg.norm(x - xo) <= 1e-4 * np.linalg.norm(xo)
 
 
 def gpu_ops(pkg, ctx, P):
@@ -391,3 +393,27 @@ def test_deflation_with_many_vectors(pkg, ctx, orc, toy):
         W = np.asfortranarray(Q[:, :nvec])
         assert_history(api.defpcg(S, b, np.zeros(n), W, M), orc.defpcg(So, b, np.zeros(n), W, Mo))
         assert_history(api.defcg(S, b, np.zeros(n), W), orc.defcg(So, b, np.zeros(n), W), So, b)
+
+
+@pytest.mark.parametrize("N,px,py,seed", [(12, 2, 1, 1), (17, 1, 3, 2), (23, 3, 3, 3), (31, 5, 2, 4), (41, 2, 5, 5),
+                                           (64, 7, 1, 6), (37, 4, 4, 7)])
+def test_shapes_sweep(pkg, ctx, orc, fem, N, px, py, seed):
+    """Odd sizes on purpose: n_Γd not a multiple of 16 (row padding), subdomains with fewer rows than a workgroup
+    tile, strips (multiplicity 2) and cross points (4), floating subdomains, very small Γ."""
+    api = pkg.api
+    mesh = fem.get_mesh(N)
+    P = fem.build_schur_problem(N, px, py, lognormal_coeff(fem, mesh.points, seed), f_m1, u0734)
+    n, b = P.sub.n_Γ, P.b_schur
+    S, M = gpu_ops(pkg, ctx, P)
+    So, Mo = orc_ops(orc, P)
+    v = np.random.default_rng(seed).standard_normal(n)
+    assert np.allclose(S * v, So * v, rtol=0, atol=1e-13 * np.abs(So * v).max())
+    assert np.allclose(M.ldiv(v), Mo * v, rtol=0, atol=1e-13 * np.abs(Mo * v).max())
+    # NN-PCG needs more than 20 iterations on the 10-16 subdomain cases ("Pcg performs worse for larger ndom",
+    # Example03:26): pass the oracle operator for the long-run branch of assert_history
+    assert_history(api.pcg(S, b, np.zeros(n), M), orc.pcg(So, b, np.zeros(n), Mo), So, b)
+    assert_history(api.pcg(S, b, v, M), orc.pcg(So, b, v, Mo), So, b)
+    assert_history(api.cg(S, b, np.zeros(n)), orc.cg(So, b, np.zeros(n)), So, b)
+    nev = min(n - 1, P.sub.ndom + 3)
+    W = lowest_eigvecs(So, n, nev)
+    assert_history(api.defpcg(S, b, np.zeros(n), W, M), orc.defpcg(So, b, np.zeros(n), W, Mo), So, b)

@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--kernel-reps", type=int, default=200)
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, RCCL communicator, all-reduces) even with one rank")
+    ap.add_argument("--shard-precond", action="store_true",
+                    help="multi-GPU: shard the Neumann-Neumann blocks like S (two all-reduces per iteration) instead of replicating them")
     ap.add_argument("--workload", choices=["schur", "fullA"], default="schur",
                     help="schur: configs[2] (headline, default). fullA: configs[1], pcg on the full matrix (CSR SpMV + BLAS-1)")
     ap.add_argument("--eps", type=float, default=1e-7, help="stop tolerance (reference constant 1e-7; other values for analysis only)")
@@ -173,8 +175,24 @@ def main():
         b_host = bs.cpu().numpy()
     else:
         b_host = P.b_schur
+    if args.force_dist and world == 1:
+        os.environ["MI355_FORCE_REDUCE"] = "1"   # one-rank rehearsal: keep the collectives of the sharded S
     S = api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(lo, hi))
-    M = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(lo, hi))
+    os.environ.pop("MI355_FORCE_REDUCE", None)
+    if multi and not args.shard_precond:
+        # S is sharded (subdomain d on GPU d, one all-reduce per S-apply). The Neumann-Neumann blocks are replicated
+        # on every rank instead (68 MB): the NN-apply is then purely local and an iteration needs ONE all-reduce.
+        Pi_all = list(P.ΠSd)
+        for d in range(ndom):
+            owner = next(r for r in range(world) if api.shard_domains(ndom, r, world)[0] <= d < api.shard_domains(ndom, r, world)[1])
+            nd = P.sub.n_Γd[d]
+            t = torch.from_numpy(np.ascontiguousarray(Pi_all[d])).cuda() if rank == owner else \
+                torch.empty((nd, nd), dtype=torch.float64, device="cuda")
+            dist.broadcast(t, owner)
+            Pi_all[d] = np.asfortranarray(t.cpu().numpy()) if rank != owner else Pi_all[d]
+        M = api.NeumannNeumannSchurPreconditioner(ctx, Pi_all, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(0, ndom))
+    else:
+        M = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(lo, hi))
     b_dev = torch.from_numpy(b_host).cuda()
     xs = [torch.zeros(n_Γ, dtype=torch.float64, device="cuda") for _ in range(args.warmup + args.steps)]
     torch.cuda.synchronize()
@@ -299,7 +317,11 @@ def main():
             "config": {"workload": f"configs[2]: N={args.N} structured P1 mesh, {n_free} free DoF, {ndom} subdomains "
                                    f"({args.px}x{args.py} boxes), lognormal a=exp(g) seed {args.seed}, n_Γ={n_Γ}; "
                                    f"pcg(S, b_schur, 0, ΠSnn), eps={args.eps:g}",
-                       "subdomains_per_gpu": hi - lo, "it": its, "loop_iterations_per_solve": loop_its,
+                       "subdomains_per_gpu": hi - lo,
+                       "parallelism": ("single GPU" if not multi else
+                                       f"S sharded {hi - lo} subdomain(s)/GPU + RCCL all-reduce of the slot table; NN blocks "
+                                       + ("sharded (2 all-reduces/iteration)" if args.shard_precond else "replicated (1 all-reduce/iteration)")),
+                       "it": its, "loop_iterations_per_solve": loop_its,
                        "final_relres": relres, "launches_per_iteration": 2 if folded else 4},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -197,6 +197,7 @@ struct LocalMaps {
   int nloc = 0;  // Σ n_Γd over local subdomains
   std::vector<int> nd, loc_off, gidx_h;
   DevBuf<int> gidx, aptr, apos, out_pos;
+  bool sharded = false;  // only a slice of the subdomains lives here and a communicator exists: Γ-sums are all-reduced
   DevBuf<int> jrank, peer, tgt;  // local-order bookkeeping of the folded PCG launches (kernels.hpp PcgFold)
   int slot_width = 1;  // W: contribution slots per Γ node (max multiplicity over this rank's subdomains)
   void build(mi_ctx_s *c, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d, const int64_t *const *gather_idx,
@@ -204,6 +205,9 @@ struct LocalMaps {
     if (ndom <= 0 || n_gamma < 0 || n_gamma >= INT32_MAX || !n_gamma_d || !gather_idx || d0 < 0 || d1 > ndom || d0 > d1)
       raise(MI_ERR_BAD_ARG, "schur/nn create: bad ndom/n_gamma/domain slice");
     ndl = (int)(d1 - d0);
+    // An operator that holds EVERY subdomain is replicated, not sharded: it never communicates, even on a context
+    // with a communicator. MI355_FORCE_REDUCE=1 keeps the collective anyway (single-GPU rehearsal of the sharded path).
+    sharded = c->comm != nullptr && (!(d0 == 0 && d1 == ndom) || env_int("MI355_FORCE_REDUCE", 0));
     int64_t tot = 0;
     for (int64_t d = d0; d < d1; ++d) {
       if (n_gamma_d[d] < 0 || n_gamma_d[d] > n_gamma) raise(MI_ERR_BAD_ARG, "n_gamma_d[%lld] out of range", (long long)d);
@@ -263,7 +267,7 @@ struct LocalMaps {
     hipLaunchKernelGGL(k_assemble, dim3(vec_grid(n_gamma)), dim3(NT), 0, c->stream, (int)n_gamma, aptr.p, apos.p, yloc,
                        y, done);
     MI_HIP(hipGetLastError());
-    c->allreduce(y, (size_t)n_gamma);
+    if (sharded) c->allreduce(y, (size_t)n_gamma);
   }
 };
 
@@ -271,7 +275,8 @@ struct LocalMaps {
 struct DenseBlockOp : Operator {
   LocalMaps maps;
   bool scale;  // true: Neumann-Neumann (gather r/cnt, result /cnt)
-  int rpw, waves, ntiles = 0, max_nd = 0;  // rows per wave, waves per workgroup (4 or 8)
+  int rpw, waves, ntiles = 0, max_nd = 0;  // rows per wave, waves per workgroup (4, 8 or 16)
+  bool reduce_over_ranks = false;          // this rank holds only a slice of the subdomains and a communicator exists
   DevBuf<double> M, cnt, yslots;
   DevBuf<double> yslots_all;  // multi-GPU: all-reduced copy of the contribution slots (every rank's subdomains)
   DevBuf<double> fold_part0, fold_part1;  // per-tile partial dots of the folded PCG launches
@@ -285,6 +290,9 @@ struct DenseBlockOp : Operator {
       : Operator(c, n_gamma), scale(node_cnt != nullptr) {
     if (!blocks) raise(MI_ERR_BAD_ARG, "dense blocks pointer is NULL");
     maps.build(c, ndom, n_gamma, n_gamma_d, gather_idx, base, d0, d1);
+    // Replicated operators (every subdomain present) never communicate — e.g. the Neumann-Neumann blocks copied to
+    // all ranks while S is sharded, which halves the all-reduces of a multi-GPU PCG iteration.
+    reduce_over_ranks = maps.sharded;
     rpw = env_int("MI355_GEMV_RPW", 2);
     if (rpw != 1 && rpw != 2 && rpw != 4) rpw = 2;
     waves = env_int("MI355_GEMV_WAVES", 16);
@@ -351,7 +359,7 @@ struct DenseBlockOp : Operator {
     hipLaunchKernelGGL(k_assemble_slots, dim3(vec_grid(n)), dim3(NT), 0, ctx->stream, (int)n, maps.slot_width,
                        yslots.p, y, done);
     MI_HIP(hipGetLastError());
-    ctx->allreduce(y, (size_t)n);
+    if (reduce_over_ranks) ctx->allreduce(y, (size_t)n);
   }
   DenseBlockOp *as_dense() override { return this; }
   // One launch of the folded PCG pair (kernels.hpp k_gemv_pcg); PHASE 1 on the ΠS operator, 0 on S.
@@ -375,7 +383,7 @@ struct DenseBlockOp : Operator {
   }
   AsmView apply_view(const double *x, double *y, const int *done) override {
     gemv(x, done);
-    if (!ctx->comm) return AsmView{yslots.p, maps.slot_width};
+    if (!reduce_over_ranks) return AsmView{yslots.p, maps.slot_width};
     // Multi-GPU: every rank wrote only its own subdomains' slots (the rest are zero), so the out-of-place sum
     // over ranks IS the full slot table (x + 0 is exact): the consumer then takes the Γ-sum in the same
     // ascending-subdomain order as on one GPU, and no separate assemble launch is needed.

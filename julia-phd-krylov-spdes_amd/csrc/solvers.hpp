@@ -151,9 +151,10 @@ struct Krylov {
   Krylov(mi_ctx_s *c, Operator *A_, Operator *M_, int nvec_)
       : ctx(c), A(A_), M(M_), ws(workspace(c, A_->n)), nvec(nvec_), n((int)A_->n), g(ws.g), s(c->stream),
         fused(A_->n <= FUSED_MAX_N && !env_int("MI355_NO_FUSED", 0)), fold(false) {
-    if (fused && M && nvec == 0 && !c->comm && !env_int("MI355_NO_FOLD", 0)) {
+    if (fused && M && nvec == 0 && !env_int("MI355_NO_FOLD", 0)) {
       Ad = A->as_dense(); Md = M->as_dense();
-      fold = Ad && Md && !Ad->scale && Md->scale && Ad->same_maps(*Md) && Ad->ntiles > 0 && Ad->max_nd <= GEMV_PANEL && Ad->maps.slot_width <= 4 &&
+      fold = Ad && Md && !Ad->reduce_over_ranks && !Md->reduce_over_ranks &&
+             !Ad->scale && Md->scale && Ad->same_maps(*Md) && Ad->ntiles > 0 && Ad->max_nd <= GEMV_PANEL && Ad->maps.slot_width <= 4 &&
              (Ad->max_nd + 64 * Ad->waves - 1) / (64 * Ad->waves) <= 8;
     }
   }

@@ -283,29 +283,40 @@ def test_error_conventions(pkg, ctx, toy):
 
 def test_rccl_single_rank_communicator(pkg, ctx, orc, micro):
     """world_size 1 on the one GPU of the box: the RCCL binding, communicator set-up and an
-    all-reduce captured inside the iteration graph all execute; the result must not change."""
+    all-reduce captured inside the iteration graph all execute; the result must not change.
+    MI355_FORCE_REDUCE keeps the collectives although the single rank holds every subdomain."""
+    import os
     api = pkg.api
     P = micro
     c2 = api.Context(0)
     c2.comm_init(c2.unique_id(), 0, 1)
     v = np.arange(5, dtype=np.float64)
     assert np.array_equal(c2.allreduce_sum(v.copy()), v)
-    S, M = gpu_ops(pkg, c2, P)
     So, Mo = orc_ops(orc, P)
-    got = api.pcg(S, P.b_schur, np.zeros(P.sub.n_Γ), M)
-    assert_history(got, orc.pcg(So, P.b_schur, np.zeros(P.sub.n_Γ), Mo))
-    # With a communicator the Γ-sums go through the all-reduced slot table and the 4-launch loop; summing with the
-    # other ranks' zeros is exact, so the result is bit-identical to the same loop without a communicator.
-    import os
+    n = P.sub.n_Γ
+    os.environ["MI355_FORCE_REDUCE"] = "1"
+    try:
+        S, M = gpu_ops(pkg, c2, P)                       # "sharded": Γ-sums through the all-reduced slot table
+    finally:
+        del os.environ["MI355_FORCE_REDUCE"]
+    Mr = api.NeumannNeumannSchurPreconditioner(c2, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)   # replicated: no collective
+    got = api.pcg(S, P.b_schur, np.zeros(n), M)
+    assert_history(got, orc.pcg(So, P.b_schur, np.zeros(n), Mo))
+    # Summing with the other ranks' zeros is exact, so the sharded loop is bit-identical to the 4-launch loop
+    # without a communicator — whether the preconditioner is sharded too or replicated on every rank.
     S1, M1 = gpu_ops(pkg, ctx, P)
     os.environ["MI355_NO_FOLD"] = "1"
     try:
-        ref = api.pcg(S1, P.b_schur, np.zeros(P.sub.n_Γ), M1)
+        ref = api.pcg(S1, P.b_schur, np.zeros(n), M1)
     finally:
         del os.environ["MI355_NO_FOLD"]
-    assert got[1] == ref[1] and np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0])
-    v = np.random.default_rng(1).standard_normal(P.sub.n_Γ)
-    assert np.array_equal(S * v, S1 * v) and np.array_equal(M.ldiv(v), M1.ldiv(v))
+    for other in (got, api.pcg(S, P.b_schur, np.zeros(n), Mr)):
+        assert other[1] == ref[1] and np.array_equal(other[2], ref[2]) and np.array_equal(other[0], ref[0])
+    v = np.random.default_rng(1).standard_normal(n)
+    assert np.array_equal(S * v, S1 * v) and np.array_equal(M.ldiv(v), M1.ldiv(v)) and np.array_equal(Mr.ldiv(v), M1.ldiv(v))
+    # a fully replicated pair on a context with a communicator is free to use the folded loop
+    Sr = api.LocalSchurs(c2, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+    assert_history(api.pcg(Sr, P.b_schur, np.zeros(n), Mr), orc.pcg(So, P.b_schur, np.zeros(n), Mo))
 
 
 # ------------------------------------------------------------------ folded PCG (2 launches / iteration) vs the other loop forms

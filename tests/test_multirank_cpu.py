@@ -34,7 +34,7 @@ def _allreduce(v):
     return t.numpy()
 
 
-def _worker(rank, world, port, N, px, py, out):
+def _worker(rank, world, port, N, px, py, out, replicate_precond):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
@@ -50,9 +50,22 @@ def _worker(rank, world, port, N, px, py, out):
     loc = list(range(lo, hi))
     gi = [P.sub.gather_idx[d] for d in loc]
     S_part = orc.apply_local_schurs_operator([P.Sd[d] for d in loc], gi, n)
-    M_part = orc.neumann_neumann_operator([P.ΠSd[d] for d in loc], gi, P.sub.node_Γ_cnt)
     S = lambda v: _allreduce(S_part(v))                         # partial apply + all-reduce
-    M = lambda v: _allreduce(M_part(v))
+    if replicate_precond:
+        # bench.py's default at N>1: the NN blocks are broadcast to every rank, the NN-apply is local (one
+        # all-reduce per iteration instead of two)
+        Pi_all = []
+        for d in range(px * py):
+            owner = next(r for r in range(world) if shard(px * py, r, world)[0] <= d < shard(px * py, r, world)[1])
+            nd = P.sub.n_Γd[d]
+            t = torch.from_numpy(np.ascontiguousarray(P.ΠSd[d])) if rank == owner else torch.empty((nd, nd), dtype=torch.float64)
+            dist.broadcast(t, owner)
+            Pi_all.append(np.asfortranarray(t.numpy()))
+        M_full = orc.neumann_neumann_operator(Pi_all, P.sub.gather_idx, P.sub.node_Γ_cnt)
+        M = lambda v: M_full(v)
+    else:
+        M_part = orc.neumann_neumann_operator([P.ΠSd[d] for d in loc], gi, P.sub.node_Γ_cnt)
+        M = lambda v: _allreduce(M_part(v))
     # pcg (cg.jl:67-109) on replicated vectors; every rank takes the same branches
     x = np.zeros(n)
     r = b - S(x)
@@ -81,10 +94,14 @@ def _worker(rank, world, port, N, px, py, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_pcg_matches_single_rank(tmp_path, fem, orc):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("replicate_precond", [False, True])
+def test_two_rank_sharded_pcg_matches_single_rank(tmp_path, fem, orc, replicate_precond):
     N, px, py, world = 40, 2, 2, 2
     out = str(tmp_path / "rank{rank}.npz")
-    mp.spawn(_worker, args=(world, _free_port(), N, px, py, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), N, px, py, out, replicate_precond), nprocs=world, join=True)
     P = fem.build_schur_problem(N, px, py, one, f_m1, u0734)
     n = P.sub.n_Γ
     S = orc.apply_local_schurs_operator(P.Sd, P.sub.gather_idx, n)

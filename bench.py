@@ -103,10 +103,29 @@ def bench_full_system(args):
                         "unit": "GB/s", "frac": round(nb / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
                         "bytes_per_launch": int(nb), "us_per_launch": round(us, 3)},
            "cpu_baseline": cpu}
-    print(json.dumps(out), flush=True)
+    OUT.emit(json.dumps(out))
+
+
+class StdoutToStderr:
+    """Everything written to fd 1 while this is active goes to stderr (RCCL prints a version banner on stdout when a
+    communicator is created); `emit` writes one line to the real stdout — the ONE JSON line of the contract."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line: str) -> None:
+        sys.stdout.flush()
+        os.write(self._saved, (line + "\n").encode())
+
+
+OUT = None
 
 
 def main():
+    global OUT
+    OUT = StdoutToStderr()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -235,7 +254,7 @@ def main():
     e0, e1 = api.Event(ctx), api.Event(ctx)
     if args.kernel_reps <= 0:      # profiling runs: leave only the solves in the trace
         if rank == 0:
-            print(json.dumps({"value": round(value, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "it": its}))
+            OUT.emit(json.dumps({"value": round(value, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "it": its}))
         return
 
     def gpu_ms(maxit, reps=30):
@@ -326,7 +345,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        OUT.emit(json.dumps(out))
     if multi:
         dist.destroy_process_group()
 

@@ -428,3 +428,41 @@ def test_shapes_sweep(pkg, ctx, orc, fem, N, px, py, seed):
     nev = min(n - 1, P.sub.ndom + 3)
     W = lowest_eigvecs(So, n, nev)
     assert_history(api.defpcg(S, b, np.zeros(n), W, M), orc.defpcg(So, b, np.zeros(n), W, Mo), So, b)
+
+
+def test_res_capacity_and_borrowed_stream(pkg, ctx, micro):
+    """C-ABI corners: res_cap smaller than `it` -> MI_ERR_RES_CAPACITY after a completed solve (the reference's
+    BoundsError on res_norm[it]); a borrowed hipStream_t (torch's) gives the same bits as the context's own."""
+    import ctypes as C
+    import torch
+    api, L = pkg.api, pkg._lib.load()
+    P = micro
+    n, b = P.sub.n_Γ, P.b_schur
+    c3 = api.Context(0)
+    S, M = gpu_ops(pkg, c3, P)
+    ref = api.pcg(S, b, np.zeros(n), M)
+    # capacity 3 < it
+    x = np.zeros(n)
+    res = np.zeros(3)
+    it = C.c_int64()
+    c3._mode_for(b, x)
+    rc = L.mi_pcg(S._h, M._h, C.c_void_p(b.ctypes.data), C.c_void_p(x.ctypes.data), 0, 1e-7,
+                  res.ctypes.data_as(C.POINTER(C.c_double)), 3, C.byref(it))
+    assert rc == pkg._lib.MI_ERR_RES_CAPACITY and it.value == ref[1]
+    assert np.array_equal(res, ref[2][:3]) and np.array_equal(x, ref[0])      # the solve itself completed
+    with pytest.raises(api.BoundsError):
+        pkg._lib.check(rc)
+    # borrowed stream
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        c3.use_torch_stream()
+        got = api.pcg(S, b, np.zeros(n), M)
+        bt = torch.from_numpy(b).cuda()
+        xt = torch.zeros(n, dtype=torch.float64, device="cuda")
+        api.pcg(S, bt, xt, M)
+        st.synchronize()
+    assert got[1] == ref[1] and np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0])
+    assert np.array_equal(xt.cpu().numpy(), ref[0])
+    assert L.mi_ctx_set_stream(c3._h, None) == 0                               # back to the context's own stream
+    again = api.pcg(S, b, np.zeros(n), M)
+    assert np.array_equal(again[0], ref[0])

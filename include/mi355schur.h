@@ -21,7 +21,7 @@
  *     outputs (`it`, `res_norm`, dot results) are always host pointers.
  *   - A context owns one HIP stream; handles are thread-compatible, not thread-safe. In
  *     multi-GPU use there is one process (or thread) and one context per GPU and every rank
- *     enters collective calls (anything on a handle created with n_ranks > 1) together.
+ *     enters collective calls (applies and solves on a SHARDED operator, see below) together.
  *   - There is no CPU fallback: with no gfx950 device mi_ctx_create fails with MI_ERR_NO_DEVICE.
  */
 #ifndef MI355SCHUR_H
@@ -64,8 +64,9 @@ int mi_ctx_set_pointer_mode(mi_ctx_t ctx, int mode);
 int mi_ctx_set_stream(mi_ctx_t ctx, void *hip_stream); /* borrow a hipStream_t; NULL = context's own */
 int mi_ctx_get_stream(mi_ctx_t ctx, void **hip_stream);
 int mi_ctx_synchronize(mi_ctx_t ctx);
-/* Iterations per captured hipGraph launch between host convergence checks (default 8);
- * 0 disables graphs (eager launches, host check every iteration). Results do not depend on it. */
+/* Iterations per follow-up hipGraph replay between host convergence checks (default 8; the first replay of a
+ * solve is sized from the previous solve with the same operators). 0 disables graphs (eager launches, host check
+ * every iteration). Results do not depend on it. */
 int mi_ctx_set_chunk(mi_ctx_t ctx, int iterations_per_graph);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI)
@@ -96,10 +97,12 @@ int mi_diag_create(mi_ctx_t ctx, int64_t n, const double *dinv, mi_op_t *op);
  *   Sd[d]          n_gamma_d[d]^2 doubles, column-major (Julia `Array(Sd[d])`)
  *   gather_idx[d]  n_gamma_d[d] entries: Γ index of Γ_d slot l (the flattened Dict ind_Γd_Γ2l[d]:
  *                  gather_idx[d][lΓd] = lΓ)
- * The local slice [dom_begin, dom_end) of the ndom subdomains is applied by this rank; the
- * per-rank partial sums are combined with an RCCL all-reduce when the context has a communicator
- * with n_ranks > 1. Pass dom_begin = 0, dom_end = ndom for single-GPU use. Arrays of the other
- * ranks' subdomains may be NULL. */
+ * The local slice [dom_begin, dom_end) of the ndom subdomains is applied by this rank. On a context with a
+ * communicator a proper slice makes the operator SHARDED: its applies end with one RCCL all-reduce (of the table of
+ * per-subdomain contributions, so the Γ-sum keeps the single-GPU order and bits). An operator created with
+ * dom_begin = 0, dom_end = ndom is REPLICATED and never communicates, with or without a communicator (single-GPU
+ * use; or e.g. the Neumann-Neumann blocks copied to every rank while S is sharded: one all-reduce per PCG
+ * iteration instead of two). Arrays of subdomains outside the slice may be NULL. */
 int mi_schur_assembled_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d,
                               const int64_t *const *gather_idx, const double *const *Sd, int index_base,
                               int64_t dom_begin, int64_t dom_end, mi_op_t *op);

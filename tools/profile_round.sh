@@ -10,9 +10,9 @@ rm -rf /tmp/prof_kt /tmp/prof_f /tmp/prof_w
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o bench -- python3 bench.py > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 cp /tmp/prof_kt/bench_kernel_stats.csv $OUT/kernel_stats.csv
 python3 tools/trace_timeline.py /tmp/prof_kt/bench_kernel_trace.csv 60 > $OUT/timeline.txt
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o pmc -- python3 bench.py --steps 10 --warmup 2 --kernel-reps 20 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o pmc -- python3 bench.py --steps 10 --warmup 2 --kernel-reps 20 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
-ls /tmp/prof_f /tmp/prof_w
-python3 tools/hbm_traffic.py /tmp/prof_f/pmc_counter_collection.csv /tmp/prof_w/pmc_counter_collection.csv $OUT/hbm_traffic.json > $OUT/hbm_traffic.log 2>&1
-tail -30 $OUT/hbm_traffic.log
+# config 2 (full-A PCG): kernel stats + the same two PMC passes, appended to the same CSVs
+rm -rf /tmp/prof_kt2 /tmp/prof_f2 /tmp/prof_w2
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt2 -o fa -- python3 bench.py --workload fullA --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_fullA_under_rocprof.json 2> /dev/null
+cp /tmp/prof_kt2/fa_kernel_stats.csv $OUT/kernel_stats_fullA.csv
+bash tools/pmc_pass.sh $TAG
 grep "mi::" $OUT/kernel_stats.csv | cut -c1-160

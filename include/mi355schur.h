@@ -41,6 +41,7 @@ extern "C" {
 #define MI_ERR_COMM (-5)         /* RCCL not loadable / communicator failure                           */
 #define MI_ERR_NO_DEVICE (-6)    /* no usable gfx950 device                                            */
 #define MI_ERR_CALLBACK (-7)     /* the interior-solve callback reported failure                       */
+#define MI_ERR_BOUNDS (-8)       /* eigCG family: an index the reference would throw BoundsError on     */
 
 #define MI_PTR_HOST 0
 #define MI_PTR_DEVICE 1
@@ -189,6 +190,36 @@ int mi_defcg(mi_op_t A, const double *b, double *x, const double *W, int64_t nve
              double eps, double *res_norm, int64_t res_cap, int64_t *it);
 int mi_defpcg(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec,
               int64_t maxit, double eps, double *res_norm, int64_t res_cap, int64_t *it);
+
+/* ---------------------------------------------------------------- eigCG family and Init-CG (recycling solvers)
+ * Reference signatures (RecyclingKrylovSolvers/eigcg.jl:27-33, 143-150; defcg.jl:111-116, 337-343; initcg.jl:28-33,
+ * 106-111; callers: Example09_DefPcgMcmcStochasticEllipticPde_Functions.jl:314, 345, 364 on the NN-preconditioned
+ * Schur system, with nvec = floor(1.25 ndom), spdim = 3 ndom):
+ *     eigcg(A,b,x,nvec,spdim;maxit=0)      eigpcg(A,b,x,M,nvec,spdim;maxit=0)
+ *     eigdefcg(A,b,x,W,spdim;maxit=0)      eigdefpcg(A,b,x,M,W,spdim;maxit=0)     -> (x, it, res_norm[1:it], V[:,1:nvec])
+ *     initcg(A,b,x,W;maxit=0)              initpcg(A,b,x,M,W;maxit=0)             -> (x, it, res_norm[1:it])
+ * x, it, res_norm as for mi_cg & co. V_out receives n x nvec doubles (column-major, host or device pointer like x):
+ * the approximate least-dominant eigenvectors of A (of M^{-1}A for the preconditioned kinds) to hand to
+ * mi_defpcg / mi_eigdefpcg / mi_initpcg as W for the next system. For the deflated kinds nvec is the column count of W.
+ * The iteration runs on the device; at each thick restart (every spdim - nev iterations) the spdim x spdim projected
+ * matrix visits the host for the dense eigen/SVD step. V_out is determined up to the sign/rotation of eigenvectors.
+ * spdim >= 2 nvec + 1 is required (MI_ERR_BOUNDS otherwise: the reference's `V[:, nev+1]` would be out of bounds);
+ * MI_ERR_BOUNDS is also returned — after x, it, res_norm have been written — where the reference's final Ritz
+ * extraction indexes out of bounds (a preconditioned solve that ends with exactly nvec search directions).
+ * initpcg: the reference's body reads an unallocated `z` (initcg.jl:127, UndefVarError); implemented as documented
+ * there (Init-PCG: deflated initial guess, then pcg). */
+int mi_eigcg(mi_op_t A, const double *b, double *x, int64_t nvec, int64_t spdim, int64_t maxit, double eps,
+             double *res_norm, int64_t res_cap, int64_t *it, double *V_out);
+int mi_eigpcg(mi_op_t A, mi_op_t M, const double *b, double *x, int64_t nvec, int64_t spdim, int64_t maxit,
+              double eps, double *res_norm, int64_t res_cap, int64_t *it, double *V_out);
+int mi_eigdefcg(mi_op_t A, const double *b, double *x, const double *W, int64_t nvec, int64_t spdim, int64_t maxit,
+                double eps, double *res_norm, int64_t res_cap, int64_t *it, double *V_out);
+int mi_eigdefpcg(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec, int64_t spdim,
+                 int64_t maxit, double eps, double *res_norm, int64_t res_cap, int64_t *it, double *V_out);
+int mi_initcg(mi_op_t A, const double *b, double *x, const double *W, int64_t nvec, int64_t maxit, double eps,
+              double *res_norm, int64_t res_cap, int64_t *it);
+int mi_initpcg(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec, int64_t maxit,
+               double eps, double *res_norm, int64_t res_cap, int64_t *it);
 
 /* ---------------------------------------------------------------- timing on the context's stream */
 int mi_event_create(mi_event_t *ev);

@@ -15,7 +15,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 MI_OK = 0
 MI_ERR_BAD_ARG, MI_ERR_HIP, MI_ERR_SINGULAR, MI_ERR_RES_CAPACITY = -1, -2, -3, -4
-MI_ERR_COMM, MI_ERR_NO_DEVICE, MI_ERR_CALLBACK = -5, -6, -7
+MI_ERR_COMM, MI_ERR_NO_DEVICE, MI_ERR_CALLBACK, MI_ERR_BOUNDS = -5, -6, -7, -8
 MI_PTR_HOST, MI_PTR_DEVICE = 0, 1
 MI_COMM_ID_BYTES = 128
 
@@ -67,6 +67,12 @@ SIGNATURES = {
     "mi_pcg": [vp, vp, vp, vp, i64, C.c_double, f64p, i64, i64p],
     "mi_defcg": [vp, vp, vp, vp, i64, i64, C.c_double, f64p, i64, i64p],
     "mi_defpcg": [vp, vp, vp, vp, vp, i64, i64, C.c_double, f64p, i64, i64p],
+    "mi_eigcg": [vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],
+    "mi_eigpcg": [vp, vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],
+    "mi_eigdefcg": [vp, vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],
+    "mi_eigdefpcg": [vp, vp, vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],
+    "mi_initcg": [vp, vp, vp, vp, i64, i64, C.c_double, f64p, i64, i64p],
+    "mi_initpcg": [vp, vp, vp, vp, vp, i64, i64, C.c_double, f64p, i64, i64p],
     "mi_event_create": [C.POINTER(vp)],
     "mi_event_record": [vp, vp],
     "mi_event_elapsed_ms": [vp, vp, f64p],
@@ -121,7 +127,7 @@ class SingularException(MiError, ArithmeticError):
 
 
 class BoundsError(MiError, IndexError):
-    """`res_norm[it]` beyond its n entries (cg.jl:23,47)."""
+    """`res_norm[it]` beyond its n entries (cg.jl:23,47); eigCG family: `V[:, nev+1]` / `eigvecs(...)[:, 1:nvec]` out of range."""
 
 
 def check(rc: int) -> None:
@@ -130,6 +136,6 @@ def check(rc: int) -> None:
     msg = load().mi_last_error().decode("utf-8", "replace")
     if rc == MI_ERR_SINGULAR:
         raise SingularException(rc, msg)
-    if rc == MI_ERR_RES_CAPACITY:
+    if rc in (MI_ERR_RES_CAPACITY, MI_ERR_BOUNDS):
         raise BoundsError(rc, msg)
     raise MiError(rc, msg)

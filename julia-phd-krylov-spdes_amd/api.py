@@ -430,7 +430,8 @@ def apply_neumann_neumann_schur(Πnn: NeumannNeumannSchurPreconditioner, r):
 
 
 # ------------------------------------------------------------------ solvers
-def _solve(kind: str, A: Operator, M: Optional[Operator], b, x, W, maxit: int, eps: float):
+def _solve(kind: str, A: Operator, M: Optional[Operator], b, x, W, maxit: int, eps: float, nvec_out: int = 0,
+           spdim: int = 0):
     ctx = A.ctx
     n = A.n
     ctx._mode_for(b, x, W)
@@ -457,16 +458,43 @@ def _solve(kind: str, A: Operator, M: Optional[Operator], b, x, W, maxit: int, e
             if kW.ndim != 2 or kW.shape[0] != n:
                 raise ValueError("W must be n x nvec")
             nvec, pW = kW.shape[1], vp(kW.ctypes.data)
+    V = pV = None
+    if kind.startswith("eig"):
+        nv = nvec if W is not None else int(nvec_out)
+        # V[:, 1:nvec] comes back where x lives: a column-major torch tensor on the device, or a Fortran numpy array
+        if _is_torch(x):
+            import torch
+            V = torch.empty((nv, n), dtype=torch.float64, device=x.device).T
+            pV = vp(V.data_ptr())
+        else:
+            V = np.empty((n, nv), order="F")
+            pV = vp(V.ctypes.data)
     if kind == "cg":
         rc = L.mi_cg(A._h, pb, px, *tail)
     elif kind == "pcg":
         rc = L.mi_pcg(A._h, M._h, pb, px, *tail)
     elif kind == "defcg":
         rc = L.mi_defcg(A._h, pb, px, pW, i64(nvec), *tail)
-    else:
+    elif kind == "defpcg":
         rc = L.mi_defpcg(A._h, M._h, pb, px, pW, i64(nvec), *tail)
+    elif kind == "initcg":
+        rc = L.mi_initcg(A._h, pb, px, pW, i64(nvec), *tail)
+    elif kind == "initpcg":
+        rc = L.mi_initpcg(A._h, M._h, pb, px, pW, i64(nvec), *tail)
+    elif kind == "eigcg":
+        rc = L.mi_eigcg(A._h, pb, px, i64(nvec_out), i64(spdim), *tail, pV)
+    elif kind == "eigpcg":
+        rc = L.mi_eigpcg(A._h, M._h, pb, px, i64(nvec_out), i64(spdim), *tail, pV)
+    elif kind == "eigdefcg":
+        rc = L.mi_eigdefcg(A._h, pb, px, pW, i64(nvec), i64(spdim), *tail, pV)
+    elif kind == "eigdefpcg":
+        rc = L.mi_eigdefpcg(A._h, M._h, pb, px, pW, i64(nvec), i64(spdim), *tail, pV)
+    else:
+        raise ValueError(kind)
     check(rc)
     k = int(it.value)
+    if V is not None:
+        return kx, k, res[:k].copy(), V
     return kx, k, res[:k].copy()
 
 
@@ -488,3 +516,33 @@ def defcg(A: Operator, b, x, W, maxit: int = 0, eps: float = EPS):
 def defpcg(A: Operator, b, x, W, M: Operator, maxit: int = 0, eps: float = EPS):
     """defpcg(A, b, x, W, M; maxit=0) (defcg.jl:242-308) — note the reference's (A,b,x,W,M) order."""
     return _solve("defpcg", A, M, b, x, W, maxit, eps)
+
+
+def eigcg(A: Operator, b, x, nvec: int, spdim: int, maxit: int = 0, eps: float = EPS):
+    """eigcg(A, b, x, nvec, spdim; maxit=0) -> (x, it, res_norm, V[:, 1:nvec]) (eigcg.jl:27-123)."""
+    return _solve("eigcg", A, None, b, x, None, maxit, eps, nvec, spdim)
+
+
+def eigpcg(A: Operator, b, x, M: Operator, nvec: int, spdim: int, maxit: int = 0, eps: float = EPS):
+    """eigpcg(A, b, x, M, nvec, spdim; maxit=0) -> (x, it, res_norm, V[:, 1:nvec]) (eigcg.jl:143-290)."""
+    return _solve("eigpcg", A, M, b, x, None, maxit, eps, nvec, spdim)
+
+
+def eigdefcg(A: Operator, b, x, W, spdim: int, maxit: int = 0, eps: float = EPS):
+    """eigdefcg(A, b, x, W, spdim; maxit=0) -> (x, it, res_norm, V[:, 1:nvec]) (defcg.jl:111-223)."""
+    return _solve("eigdefcg", A, None, b, x, W, maxit, eps, 0, spdim)
+
+
+def eigdefpcg(A: Operator, b, x, M: Operator, W, spdim: int, maxit: int = 0, eps: float = EPS):
+    """eigdefpcg(A, b, x, M, W, spdim; maxit=0) -> (x, it, res_norm, V[:, 1:nvec]) (defcg.jl:337-473) — (A,b,x,M,W) order."""
+    return _solve("eigdefpcg", A, M, b, x, W, maxit, eps, 0, spdim)
+
+
+def initcg(A: Operator, b, x, W, maxit: int = 0, eps: float = EPS):
+    """initcg(A, b, x, W; maxit=0) (initcg.jl:28-75)."""
+    return _solve("initcg", A, None, b, x, W, maxit, eps)
+
+
+def initpcg(A: Operator, b, x, M: Operator, W, maxit: int = 0, eps: float = EPS):
+    """initpcg(A, b, x, M, W; maxit=0) (initcg.jl:106-160)."""
+    return _solve("initpcg", A, M, b, x, W, maxit, eps)

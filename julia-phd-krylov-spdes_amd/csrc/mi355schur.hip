@@ -3,7 +3,7 @@
 
 #include <tuple>
 
-#include "solvers.hpp"
+#include "eig_solvers.hpp"
 
 namespace mi {
 
@@ -87,6 +87,67 @@ static int run_solver(mi_op_t A, mi_op_t M, const double *b, double *x, const do
     In wi(c, W, want_W ? n * (size_t)nvec : 0, wstage);
     Krylov k(c, a, m, want_W ? (int)nvec : 0);
     const int rc = k.solve(bi.dev, xi.dev, wi.dev, maxit, eps, res_norm, res_cap, it);
+    xi.finish();
+    return rc;
+  });
+}
+
+static int run_eig_solver(EigKind kind, mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec,
+                          int64_t spdim, int64_t maxit, double eps, double *res_norm, int64_t res_cap, int64_t *it,
+                          double *V_out) {
+  const bool want_M = kind == EIGPCG || kind == EIGDEFPCG, want_W = kind == EIGDEFCG || kind == EIGDEFPCG;
+  if (!A || !A->impl || !b || !x || !it || res_cap < 0 || (res_cap > 0 && !res_norm) || maxit < 0)
+    return fail(MI_ERR_BAD_ARG, "solver: NULL or negative argument");
+  if (want_M && (!M || !M->impl)) return fail(MI_ERR_BAD_ARG, "solver: preconditioner handle is NULL");
+  if (nvec < 1 || nvec > 512 || spdim > 4096 || (want_W && !W)) return fail(MI_ERR_BAD_ARG, "solver: bad W / nvec / spdim");
+  if (spdim < 2 * nvec + 1)
+    return fail(MI_ERR_BOUNDS, "spdim = %lld < 2 nvec + 1 = %lld: V[:, nev + 1] can fall outside the search space (BoundsError)",
+                (long long)spdim, (long long)(2 * nvec + 1));
+  Operator *a = A->impl.get(), *m = want_M ? M->impl.get() : nullptr;
+  if (m && (m->n != a->n || m->ctx != a->ctx)) return fail(MI_ERR_BAD_ARG, "solver: A and M differ in size or context");
+  mi_ctx_s *c = a->ctx;
+  return guarded([&]() -> int {
+    c->use();
+    const size_t n = (size_t)a->n;
+    In bi(c, b, n, c->scratch_a);
+    InOut xi(c, x, n, c->scratch_b, true);
+    DevBuf<double> wstage, vstage;
+    In wi(c, W, want_W ? n * (size_t)nvec : 0, wstage);
+    InOut vi(c, V_out, V_out ? n * (size_t)nvec : 0, vstage, false);
+    EigKrylov k(c, a, m, kind, (int)nvec, (int)spdim);
+    const int rc = k.solve(bi.dev, xi.dev, wi.dev, maxit, eps, res_norm, res_cap, it, V_out ? vi.dev : nullptr);
+    xi.finish();
+    vi.finish();
+    return rc;
+  });
+}
+
+// initcg / initpcg (initcg.jl:28-75, 106-160): x += W (WtAW \ W'(b - A x)), then cg / pcg from that guess.
+static int run_init_solver(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec, int64_t maxit,
+                           double eps, double *res_norm, int64_t res_cap, int64_t *it, bool want_M) {
+  if (!A || !A->impl || !b || !x || !it || res_cap < 0 || (res_cap > 0 && !res_norm) || maxit < 0)
+    return fail(MI_ERR_BAD_ARG, "solver: NULL or negative argument");
+  if (want_M && (!M || !M->impl)) return fail(MI_ERR_BAD_ARG, "solver: preconditioner handle is NULL");
+  if (nvec < 1 || !W || nvec > 1024) return fail(MI_ERR_BAD_ARG, "solver: bad W / nvec");
+  Operator *a = A->impl.get(), *m = want_M ? M->impl.get() : nullptr;
+  if (m && (m->n != a->n || m->ctx != a->ctx)) return fail(MI_ERR_BAD_ARG, "solver: A and M differ in size or context");
+  mi_ctx_s *c = a->ctx;
+  return guarded([&]() -> int {
+    c->use();
+    const size_t n = (size_t)a->n;
+    In bi(c, b, n, c->scratch_a);
+    InOut xi(c, x, n, c->scratch_b, true);
+    DevBuf<double> wstage;
+    In wi(c, W, n * (size_t)nvec, wstage);
+    {
+      Krylov guess(c, a, nullptr, (int)nvec, /*generic=*/true);
+      int64_t mx = maxit, cap = 0;
+      double e = eps;
+      guess.begin(bi.dev, xi.dev, wi.dev, mx, e, cap);   // leaves the deflated guess in the workspace's x
+      MI_HIP(hipMemcpyAsync(xi.dev, guess.ws.x, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    Krylov k(c, a, m, 0);
+    const int rc = k.solve(bi.dev, xi.dev, nullptr, maxit, eps, res_norm, res_cap, it);
     xi.finish();
     return rc;
   });
@@ -473,6 +534,31 @@ int mi_defcg(mi_op_t A, const double *b, double *x, const double *W, int64_t nve
 int mi_defpcg(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec, int64_t maxit,
               double eps, double *res_norm, int64_t res_cap, int64_t *it) {
   return run_solver(A, M, b, x, W, nvec, maxit, eps, res_norm, res_cap, it, true, true);
+}
+
+int mi_eigcg(mi_op_t A, const double *b, double *x, int64_t nvec, int64_t spdim, int64_t maxit, double eps,
+             double *res_norm, int64_t res_cap, int64_t *it, double *V_out) {
+  return run_eig_solver(EIGCG, A, nullptr, b, x, nullptr, nvec, spdim, maxit, eps, res_norm, res_cap, it, V_out);
+}
+int mi_eigpcg(mi_op_t A, mi_op_t M, const double *b, double *x, int64_t nvec, int64_t spdim, int64_t maxit, double eps,
+              double *res_norm, int64_t res_cap, int64_t *it, double *V_out) {
+  return run_eig_solver(EIGPCG, A, M, b, x, nullptr, nvec, spdim, maxit, eps, res_norm, res_cap, it, V_out);
+}
+int mi_eigdefcg(mi_op_t A, const double *b, double *x, const double *W, int64_t nvec, int64_t spdim, int64_t maxit,
+                double eps, double *res_norm, int64_t res_cap, int64_t *it, double *V_out) {
+  return run_eig_solver(EIGDEFCG, A, nullptr, b, x, W, nvec, spdim, maxit, eps, res_norm, res_cap, it, V_out);
+}
+int mi_eigdefpcg(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec, int64_t spdim,
+                 int64_t maxit, double eps, double *res_norm, int64_t res_cap, int64_t *it, double *V_out) {
+  return run_eig_solver(EIGDEFPCG, A, M, b, x, W, nvec, spdim, maxit, eps, res_norm, res_cap, it, V_out);
+}
+int mi_initcg(mi_op_t A, const double *b, double *x, const double *W, int64_t nvec, int64_t maxit, double eps,
+              double *res_norm, int64_t res_cap, int64_t *it) {
+  return run_init_solver(A, nullptr, b, x, W, nvec, maxit, eps, res_norm, res_cap, it, false);
+}
+int mi_initpcg(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec, int64_t maxit, double eps,
+               double *res_norm, int64_t res_cap, int64_t *it) {
+  return run_init_solver(A, M, b, x, W, nvec, maxit, eps, res_norm, res_cap, it, true);
 }
 
 // ---------------------------------------------------------------- events

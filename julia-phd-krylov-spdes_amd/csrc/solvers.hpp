@@ -16,6 +16,7 @@
 #include <cstddef>
 #include <tuple>
 
+#include "eig_kernels.hpp"
 #include "operators.hpp"
 
 namespace mi {
@@ -35,8 +36,9 @@ constexpr int64_t RES_STAGE = 8192;
 struct GraphKey {
   const Operator *A, *M;
   int nvec, chunk;  // chunk > 0: that many iterations; chunk < 0: set-up + (-chunk) iterations
+  int tag = 0;      // 0: cg/pcg/defcg/defpcg; eigCG family: 1 + kind + 8*spdim (recording kernels ride on the iteration)
   bool operator<(const GraphKey &o) const {
-    return std::tie(A, M, nvec, chunk) < std::tie(o.A, o.M, o.nvec, o.chunk);
+    return std::tie(A, M, nvec, chunk, tag) < std::tie(o.A, o.M, o.nvec, o.chunk, o.tag);
   }
 };
 
@@ -54,6 +56,12 @@ struct SolverWorkspace {
   DevBuf<double> W, AW, LU, mu, part_mu, gram;
   DevBuf<int> piv;
   int nvec_cap = 0;
+  // eigCG family (eig_solvers.hpp): search space V (n x spdim), A*V (eigpcg), rotation target, tvec, VtAV, ...
+  DevBuf<double> eV, eAV, eVtmp, etvec, eT, eG, epart, eLUw, emu2;
+  DevBuf<int> epivw;
+  DevBuf<EigState> ees;
+  int e_spdim = 0, e_nvec = 0;
+  bool e_av = false;
   PinnedFlags *flags = nullptr;    // 2 slots, pinned
   PinnedParams *params = nullptr;  // pinned source of eps / maxit / res_cap
   double *res_stage = nullptr;     // pinned landing zone for short residual histories
@@ -105,6 +113,16 @@ struct SolverWorkspace {
     mu.alloc(nvec); piv.alloc(nvec); part_mu.alloc((size_t)nvec * MAX_PARTS);
     nvec_cap = nvec;
   }
+  void ensure_eig(int spdim, int nvec, bool need_av) {
+    if (spdim <= e_spdim && nvec <= e_nvec && (!need_av || e_av)) return;
+    drop_graphs();
+    spdim = std::max(spdim, e_spdim); nvec = std::max(nvec, e_nvec); need_av = need_av || e_av;
+    eV.alloc((size_t)n * spdim); eVtmp.alloc((size_t)n * 2 * nvec); etvec.alloc((size_t)n);
+    if (need_av) eAV.alloc((size_t)n * spdim);
+    eT.alloc((size_t)spdim * spdim); eG.alloc((size_t)spdim * 2 * nvec); epart.alloc((size_t)2 * nvec * MAX_PARTS);
+    eLUw.alloc((size_t)nvec * nvec); emu2.alloc(nvec); epivw.alloc(nvec); ees.alloc(1);
+    e_spdim = spdim; e_nvec = nvec; e_av = need_av;
+  }
 };
 
 inline SolverWorkspace &workspace(mi_ctx_s *ctx, int64_t n) {
@@ -147,10 +165,17 @@ struct Krylov {
   bool fused;  // single-workgroup loop kernels (small Γ systems)
   bool fold;   // pcg with both operators dense on the same maps: vector work folded into the two GEMVs
   DenseBlockOp *Ad = nullptr, *Md = nullptr;
+  // eigCG family: recording kernels after every iteration (eig_solvers.hpp fills this in)
+  struct EigHook {
+    int tag = 0, spdim = 0;
+    bool has_tvec = false;   // eigcg / eigpcg keep tvec and the coupling column
+    bool project_r = false;  // eigdefpcg: r .-= W * (WtW \ (W' * r)) before rTr (defcg.jl:411)
+  } eig;
+  std::vector<double> gram_host;  // WtAW as computed (before LU), kept for VtAV[1:nvec,1:nvec] (defcg.jl:158 / 391)
 
-  Krylov(mi_ctx_s *c, Operator *A_, Operator *M_, int nvec_)
+  Krylov(mi_ctx_s *c, Operator *A_, Operator *M_, int nvec_, bool generic = false)
       : ctx(c), A(A_), M(M_), ws(workspace(c, A_->n)), nvec(nvec_), n((int)A_->n), g(ws.g), s(c->stream),
-        fused(A_->n <= FUSED_MAX_N && !env_int("MI355_NO_FUSED", 0)), fold(false) {
+        fused(!generic && A_->n <= FUSED_MAX_N && !env_int("MI355_NO_FUSED", 0)), fold(false) {
     if (fused && M && nvec == 0 && !env_int("MI355_NO_FOLD", 0)) {
       Ad = A->as_dense(); Md = M->as_dense();
       fold = Ad && Md && !Ad->reduce_over_ranks && !Md->reduce_over_ranks &&
@@ -184,10 +209,22 @@ struct Krylov {
     MI_HIP(hipGetLastError());
   }
   // mu = WtAW \ (V' v), V = AW (loop) or W (set-up)
-  void project(const double *V, const double *v, const int *dn) {
+  void project(const double *V, const double *v, const int *dn) { project(V, v, dn, ws.LU.p, ws.piv.p, ws.mu.p); }
+  void project(const double *V, const double *v, const int *dn, const double *LU, const int *piv, double *mu) {
     hipLaunchKernelGGL(k_multi_dot_partial, dim3(g, nvec), dim3(NT), 0, s, n, V, v, ws.part_mu.p, dn);
-    hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(64), sizeof(double) * nvec, s, nvec, ws.LU.p, ws.piv.p, ws.part_mu.p, g,
-                       ws.mu.p, dn);
+    hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(64), sizeof(double) * nvec, s, nvec, LU, piv, ws.part_mu.p, g, mu, dn);
+    MI_HIP(hipGetLastError());
+  }
+  // Lanczos bookkeeping of the eigCG family for the iteration just enqueued (z: what p was updated with)
+  void eig_record(const double *zz) {
+    const int pre = M != nullptr;
+    double *tv = eig.has_tvec ? ws.etvec.p : nullptr;
+    hipLaunchKernelGGL(k_eig_vec, dim3(g), dim3(NT), 0, s, n, ws.st, ws.ees.p, pre, eig.spdim, zz, ws.Ap, ws.eV.p, tv);
+    if (eig.has_tvec)
+      hipLaunchKernelGGL(k_eig_coupling, dim3(g, 2 * ws.e_nvec), dim3(NT), 0, s, n, ws.st, ws.ees.p, ws.eV.p, ws.etvec.p,
+                         ws.epart.p);
+    hipLaunchKernelGGL(k_eig_state, dim3(1), dim3(64), 0, s, ws.st, ws.ees.p, ws.eT.p, eig.spdim, ws.epart.p, g,
+                       (int)eig.has_tvec);
     MI_HIP(hipGetLastError());
   }
 
@@ -252,9 +289,13 @@ struct Krylov {
       part = ws.part_pAp; npart = g;
     }
     const double *dinv = nullptr;
-    const int diag = pre ? M->diag_kind(&dinv) : 0;
+    const int diag = pre && !eig.project_r ? M->diag_kind(&dinv) : 0;
     hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(NT), 0, s, n, ws.st, part, npart, ws.p, ws.Ap, ws.x, ws.r,
                        ws.part_rr, pre, diag, dinv, ws.z, ws.part_rz);  // alpha; x += alpha p; r -= alpha Ap; r'r [; z; r'z]
+    if (eig.project_r) {                                                // r .-= W * (WtW \ (W' * r)); rTr = dot(r, r)
+      project(ws.W.p, ws.r, dn, ws.eLUw.p, ws.epivw.p, ws.emu2.p);
+      hipLaunchKernelGGL(k_project_r, dim3(g), dim3(NT), 0, s, n, ws.r, ws.W.p, ws.emu2.p, nvec, ws.part_rr, dn);
+    }
     const double *zz = ws.r;
     if (pre) {
       if (!diag) {
@@ -266,6 +307,7 @@ struct Krylov {
     if (nvec > 0) project(ws.AW.p, zz, dn);                           // mu .= WtAW \ (WtA * z)
     hipLaunchKernelGGL(k_update_p, dim3(g), dim3(NT), 0, s, n, ws.st, ws.part_rr, ws.part_rz, g, zz, ws.p, Wp, mup, nvec,
                        ws.res_norm.p, pre);                           // beta; p; it += 1; res_norm[it]; stop rule
+    if (eig.tag) eig_record(zz);
     MI_HIP(hipGetLastError());
   }
 
@@ -311,7 +353,7 @@ struct Krylov {
 
   // chunk > 0: `chunk` iterations; chunk < 0: set-up tail + (-chunk) iterations.
   hipGraphExec_t graph(int chunk) {
-    GraphKey key{A, M, nvec, chunk};
+    GraphKey key{A, M, nvec, chunk, eig.tag};
     auto it = ws.graphs.find(key);
     if (it != ws.graphs.end()) return it->second;
     hipGraph_t gr = nullptr;
@@ -340,42 +382,53 @@ struct Krylov {
     MI_HIP(hipEventRecord(ws.ev[slot], s));
   }
 
-  // b_in / x_io / W_in are device pointers here (host mode is staged by the caller).
-  int solve(const double *b_in, double *x_io, const double *W_in, int64_t maxit, double eps, double *res_host,
-            int64_t res_cap, int64_t *it_out) {
+  // Common entry of every solver: b, x to the workspace; eps / maxit / res_cap to the state block; deflated
+  // solvers: W, WtA, WtAW (LU on the host) and the deflated initial guess (defcg.jl:40-54 / 260-275).
+  void begin(const double *b_in, const double *x_in, const double *W_in, int64_t &maxit, double &eps, int64_t &cap_dev) {
     if (eps <= 0.0) eps = 1e-7;           // RecyclingKrylovSolvers.jl:21
     if (maxit == 0) maxit = n;            // cg.jl:25
-    const int64_t cap_dev = std::min<int64_t>(maxit, (int64_t)n) + 1;  // reference: res_norm has n entries
+    cap_dev = std::min<int64_t>(maxit, (int64_t)n) + 1;  // reference: res_norm has n entries
     if ((size_t)cap_dev > ws.res_norm.n) { ws.drop_graphs(); ws.res_norm.alloc((size_t)cap_dev); }
     if (nvec > 0) ws.ensure_deflation(nvec);
     const size_t vb = sizeof(double) * (size_t)n;
     MI_HIP(hipMemcpyAsync(ws.b, b_in, vb, hipMemcpyDeviceToDevice, s));
-    MI_HIP(hipMemcpyAsync(ws.x, x_io, vb, hipMemcpyDeviceToDevice, s));
+    MI_HIP(hipMemcpyAsync(ws.x, x_in, vb, hipMemcpyDeviceToDevice, s));
     *ws.params = PinnedParams{eps, (long long)maxit, (long long)cap_dev};
     MI_HIP(hipMemcpyAsync(&ws.st->eps, &ws.params->eps, sizeof(double), hipMemcpyHostToDevice, s));
     MI_HIP(hipMemcpyAsync(&ws.st->maxit, &ws.params->maxit, 2 * sizeof(long long), hipMemcpyHostToDevice, s));
-
     if (nvec > 0) {
-      // defcg.jl:40-54 / 260-275
       MI_HIP(hipMemcpyAsync(ws.W.p, W_in, vb * nvec, hipMemcpyDeviceToDevice, s));
       for (int v = 0; v < nvec; ++v) A->apply(ws.W.p + (size_t)v * n, ws.AW.p + (size_t)v * n, nullptr);  // WtA[v,:] = A*W[:,v]
       hipLaunchKernelGGL(k_small_gram, dim3(nvec, nvec), dim3(NT), 0, s, n, ws.AW.p, ws.W.p, ws.gram.p, nvec);  // WtAW
       MI_HIP(hipGetLastError());
-      std::vector<double> lu((size_t)nvec * nvec);
-      MI_HIP(hipMemcpyAsync(lu.data(), ws.gram.p, sizeof(double) * lu.size(), hipMemcpyDeviceToHost, s));
-      MI_HIP(hipStreamSynchronize(s));
-      std::vector<int> piv;
-      const int info = host_lu(nvec, lu, piv);
-      if (info) raise(MI_ERR_SINGULAR, "WtAW is singular: U[%d,%d] == 0 (SingularException(%d))", info, info, info);
-      ws.LU.upload(lu.data(), lu.size(), s);
-      ws.piv.upload(piv.data(), piv.size(), s);
-      MI_HIP(hipStreamSynchronize(s));
+      factor(ws.gram.p, ws.LU, ws.piv, &gram_host, "WtAW");
       A->apply(ws.x, ws.Ap, nullptr);                                        // r .= b .- A*x
       hipLaunchKernelGGL(k_residual, dim3(g), dim3(NT), 0, s, n, ws.b, ws.Ap, ws.r, ws.part_rr, ws.part_bb);
       project(ws.W.p, ws.r, nullptr);                                        // mu = WtAW \ (W'r)
       hipLaunchKernelGGL(k_add_Wmu, dim3(g), dim3(NT), 0, s, n, ws.x, ws.W.p, ws.mu.p, nvec);  // x .+= W*mu
       MI_HIP(hipGetLastError());
     }
+  }
+  // LU (host, LAPACK getrf order) of the nvec x nvec device matrix `gram`; factors and pivots back to the device.
+  void factor(const double *gram, DevBuf<double> &LU, DevBuf<int> &piv, std::vector<double> *keep, const char *name) {
+    std::vector<double> lu((size_t)nvec * nvec);
+    MI_HIP(hipMemcpyAsync(lu.data(), gram, sizeof(double) * lu.size(), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    if (keep) *keep = lu;
+    std::vector<int> pv;
+    const int info = host_lu(nvec, lu, pv);
+    if (info) raise(MI_ERR_SINGULAR, "%s is singular: U[%d,%d] == 0 (SingularException(%d))", name, info, info, info);
+    LU.upload(lu.data(), lu.size(), s);
+    piv.upload(pv.data(), pv.size(), s);
+    MI_HIP(hipStreamSynchronize(s));
+  }
+
+  // b_in / x_io / W_in are device pointers here (host mode is staged by the caller).
+  int solve(const double *b_in, double *x_io, const double *W_in, int64_t maxit, double eps, double *res_host,
+            int64_t res_cap, int64_t *it_out) {
+    int64_t cap_dev = 0;
+    begin(b_in, x_io, W_in, maxit, eps, cap_dev);
+    const size_t vb = sizeof(double) * (size_t)n;
 
     // ---- set-up tail + loop
     bool use_graph = ctx->chunk > 0 && A->graph_safe() && (!M || M->graph_safe()) && !ctx->no_graph;

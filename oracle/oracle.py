@@ -257,3 +257,211 @@ def interior_cg(A: sp.spmatrix, b, reltol: float = 1e-9):
 def interior_cg_solvers(A_IIdd, reltol: float = 1e-9):
     """Per-subdomain callables for apply_local_schurs_matfree_operator: the reference's inexact interior solve."""
     return [lambda rhs, A=A: interior_cg(A, rhs, reltol)[0] for A in A_IIdd]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# eigCG family and Init-CG (SURVEY.md §8 row f1): numpy restatement, one reference statement per line.
+# Dense small-matrix calls follow Julia's LinearAlgebra semantics:
+#   eigvecs(Symmetric(T))  -> eigh on the UPPER triangle, ascending
+#   rank(Y)                -> #{σ_i > min(m,n)·eps·σ_1}            (stdlib default rtol)
+#   svd(Y).U               -> thin U
+#   eigen(H)               -> symmetric solver when H is exactly symmetric, else the general one sorted by real part
+# The Krylov part (x, it, res_norm) does not depend on any of this for eigcg/eigpcg; the returned V[:, 1:nvec] is
+# defined up to the sign (and, for clustered Ritz values, rotation) of eigenvectors, so tests compare subspaces.
+
+class BoundsError(IndexError):
+    """Julia's BoundsError where the reference indexes out of range."""
+
+
+def _julia_rank(Y):
+    s = np.linalg.svd(Y, compute_uv=False)
+    if s.size == 0 or s[0] == 0.0:
+        return 0
+    return int(np.sum(s > min(Y.shape) * np.finfo(float).eps * s[0]))
+
+
+def _eigvecs_sym_upper(T):
+    return np.linalg.eigh(np.triu(T) + np.triu(T, 1).T)[1]
+
+
+def _eigen(H, symmetric):
+    if symmetric or np.array_equal(H, H.T):
+        return np.linalg.eigh(np.triu(H) + np.triu(H, 1).T)
+    vals, Z = np.linalg.eig(H)
+    if np.iscomplexobj(vals):
+        if np.max(np.abs(vals.imag)) > 0:
+            raise TypeError("eigen(H) returned complex eigenvalues (TypeError on the ::Eigen{T,T,...} assertion)")
+        vals, Z = vals.real, Z.real
+    o = np.argsort(vals, kind="stable")
+    return vals[o], Z[:, o]
+
+
+def _ritz_restart(VtAV, m, nvec, sym_H):
+    """eigcg.jl:92-99 / 244-253 / 273-282 on the leading m x m block: returns (vals, Q*Z, nev)."""
+    Tm = np.triu(VtAV[:m, :m]) + np.triu(VtAV[:m, :m], 1).T
+    Y = np.zeros((m, 2 * nvec))
+    Y[:, :nvec] = np.linalg.eigh(Tm)[1][:, :nvec]
+    Y[:m - 1, nvec:] = np.linalg.eigh(Tm[:m - 1, :m - 1])[1][:, :nvec]
+    nev = _julia_rank(Y)
+    Q = np.linalg.svd(Y, full_matrices=False)[0][:, :nev]
+    H = Q.T @ (Tm @ Q)
+    vals, Z = _eigen(H, sym_H)
+    return vals, Q @ Z, nev
+
+
+def _eig_solver(A, b, x, M, W, nvec, spdim, maxit, eps, kind):
+    """Shared body of eigcg (eigcg.jl:27-123), eigpcg (:143-267), eigdefcg (defcg.jl:111-223), eigdefpcg (:337-473)."""
+    pre = M is not None
+    deflated = W is not None
+    n = A.n
+    b = _f64(b)
+    x = np.array(x, dtype=np.float64, copy=True)
+    if deflated:
+        W = np.asfortranarray(W, dtype=np.float64)
+        nvec = W.shape[1]
+    if spdim < 2 * nvec + 1:
+        raise BoundsError("ivec = nev + 1 can exceed spdim")
+    V = np.zeros((n, spdim), order="F")
+    VtAV = np.zeros((spdim, spdim))
+    tvec = np.zeros(n)
+    res_norm = np.empty(max(n, 1))
+    just_restarted = False
+    first_restart = True
+    hlpr = 0.0
+    if maxit == 0:
+        maxit = n
+    if deflated:
+        WtA = np.empty((nvec, n))
+        for i in range(nvec):
+            WtA[i, :] = A(W[:, i])                                   # defcg.jl:128-131 / 360-363
+        WtAW = WtA @ W
+        if pre:
+            WtW = W.T @ W                                            # defcg.jl:369
+        r = b - A(x)
+        x += W @ lu_solve(WtAW, W.T @ r)                             # defcg.jl:139-141 / 373-375
+    it = 1
+    r = b - A(x)
+    rTr = r @ r
+    z = M(r) if pre else r
+    rTz = r @ z if pre else rTr
+    if deflated:
+        p = z - W @ lu_solve(WtAW, WtA @ z)
+        VtAV[:nvec, :nvec] = WtAW
+        V[:, :nvec] = W
+        ivec = nvec + 1
+    else:
+        p = z.copy()
+        ivec = 1
+    res_norm[0] = np.sqrt(rTr)
+    V[:, ivec - 1] = z / np.sqrt(rTz) if pre else r / res_norm[0]
+    tol = eps * np.sqrt(b @ b)
+    while it < maxit and res_norm[it - 1] > tol:
+        Ap = A(p)
+        d = p @ Ap
+        num = rTz if pre else rTr
+        alpha = num / d
+        beta = 1.0 / num
+        x += alpha * p
+        r += (-alpha) * Ap
+        if deflated and pre:
+            r -= W @ lu_solve(WtW, W.T @ r)                          # defcg.jl:411
+        rTr = r @ r
+        if pre:
+            z = M(r)
+            if just_restarted and not deflated:
+                hlpr = np.sqrt(rTz)                                  # eigcg.jl:212-214
+            rTz = r @ z
+            beta *= rTz
+        else:
+            z = r
+            beta *= rTr
+        if not deflated and ivec == spdim:
+            tvec -= beta * Ap                                        # eigcg.jl:71-73 / 217-219
+        if deflated:
+            p = beta * p + z - W @ lu_solve(WtAW, WtA @ z)
+        else:
+            p = beta * p + z
+        it += 1
+        res_norm[it - 1] = np.sqrt(rTr)
+        vnew = (lambda: z / np.sqrt(rTz)) if pre else (lambda: r / res_norm[it - 1])
+
+        VtAV[ivec - 1, ivec - 1] += 1.0 / alpha
+        if not deflated and just_restarted:
+            tvec += Ap
+            nev = ivec - 1
+            scale = hlpr if pre else res_norm[it - 2]
+            VtAV[:nev, ivec - 1] = V[:, :nev].T @ (tvec / scale)     # eigcg.jl:79-84 / 225-230
+            just_restarted = False
+        if ivec == spdim:
+            if deflated:
+                if first_restart:
+                    VtAV[:nvec, nvec:spdim] = WtA @ V[:, nvec:spdim]  # defcg.jl:186-189 / 422-425
+                    first_restart = False
+            elif pre:
+                AV = np.empty((n, spdim), order="F")
+                for j in range(spdim):
+                    AV[:, j] = A(V[:, j])                            # eigcg.jl:233-240
+                VtAV[:, :] = V.T @ AV
+            vals, QZ, nev = _ritz_restart(VtAV, spdim, nvec, sym_H=pre)
+            V[:, :nev] = V @ QZ
+            ivec = nev + 1
+            V[:, ivec - 1] = vnew()
+            VtAV[:, :] = 0.0
+            VtAV[np.arange(nev), np.arange(nev)] = vals[:nev]
+            VtAV[ivec - 1, ivec - 1] = beta / alpha
+            if not deflated:
+                tvec = -beta * Ap
+            just_restarted = True
+        else:
+            if deflated:
+                just_restarted = False                               # defcg.jl:444 (eigdefpcg only; unused in eigdefcg)
+            ivec += 1
+            V[:, ivec - 1] = vnew()
+            VtAV[ivec - 2, ivec - 1] = -np.sqrt(beta) / alpha
+            VtAV[ivec - 1, ivec - 1] = beta / alpha
+    if pre and not just_restarted:                                   # eigcg.jl:269-287 / defcg.jl:451-470 (pcg variants only)
+        if ivec > nvec:
+            ivec -= 1
+            if deflated and first_restart:
+                VtAV[:nvec, nvec:ivec] = WtA @ V[:, nvec:ivec]
+            if ivec - 1 < nvec:
+                # eigvecs(Tm[1:ivec-1, 1:ivec-1])[:, 1:nvec] (eigcg.jl:275 / defcg.jl:461) is out of range
+                raise BoundsError(f"attempt to access {ivec - 1} x {ivec - 1} eigenvector matrix at columns 1:{nvec}")
+            vals, QZ, nev = _ritz_restart(VtAV, ivec, nvec, sym_H=True)
+            V[:, :nev] = V[:, :ivec] @ QZ
+    return x, it, res_norm[:it].copy(), V[:, :nvec].copy()
+
+
+def eigcg(A, b, x, nvec, spdim, maxit=0, eps=1e-7):
+    return _eig_solver(A, b, x, None, None, nvec, spdim, maxit, eps, "eigcg")
+
+
+def eigpcg(A, b, x, M, nvec, spdim, maxit=0, eps=1e-7):
+    return _eig_solver(A, b, x, M, None, nvec, spdim, maxit, eps, "eigpcg")
+
+
+def eigdefcg(A, b, x, W, spdim, maxit=0, eps=1e-7):
+    return _eig_solver(A, b, x, None, W, 0, spdim, maxit, eps, "eigdefcg")
+
+
+def eigdefpcg(A, b, x, M, W, spdim, maxit=0, eps=1e-7):
+    return _eig_solver(A, b, x, M, W, 0, spdim, maxit, eps, "eigdefpcg")
+
+
+def _init_guess(A, b, x, W):
+    """initcg.jl:42-49 / 119-125: x += W (WtAW \\ W'(b - A x)) with WtA = W'A (rows A*W[:,i] on a symmetric A)."""
+    W = np.asfortranarray(W, dtype=np.float64)
+    x = np.array(x, dtype=np.float64, copy=True)
+    WtA = np.empty((W.shape[1], A.n))
+    for i in range(W.shape[1]):
+        WtA[i, :] = A(W[:, i])
+    r = _f64(b) - A(x)
+    return x + W @ lu_solve(WtA @ W, W.T @ r)
+
+
+def initcg(A, b, x, W, maxit=0, eps=1e-7):
+    return cg(A, b, _init_guess(A, b, x, W), maxit, eps)
+
+
+def initpcg(A, b, x, M, W, maxit=0, eps=1e-7):
+    return pcg(A, b, _init_guess(A, b, x, W), M, maxit, eps)

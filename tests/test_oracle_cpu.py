@@ -302,3 +302,56 @@ def test_interior_cg_restates_iterative_solvers(orc, micro):
                                                  orc.interior_cg_solvers(P.A_IIdd, 1e-9))
     v = P.b_schur
     assert np.allclose(Si(v), Se(v), rtol=0, atol=1e-7 * np.abs(Se(v)).max())
+
+
+# ------------------------------------------------------------------ eigCG family, oracle-level pins
+def _lap2d(m):
+    import scipy.sparse as sp
+    k = m - 5                                   # rectangular + anisotropic: simple eigenvalues (a Krylov space sees one
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(m, m))      # vector per eigenspace only)
+    U = sp.diags([-1.3, 2.6, -1.3], [-1, 0, 1], shape=(k, k))
+    return sp.csc_matrix(sp.kron(sp.identity(k), T) + sp.kron(U, sp.identity(m)) + 0.05 * sp.identity(m * k))
+
+
+def test_eig_family_known_answers(orc):
+    """Properties the algorithms guarantee (no reference fixture exists): the Krylov part of eigcg/eigpcg IS cg/pcg;
+    the returned vectors converge to the least-dominant eigenvectors; Def-CG with them needs fewer iterations;
+    eigdefpcg keeps r orthogonal to W; Init-CG's first residual is W-orthogonal."""
+    A = _lap2d(24)
+    n = A.shape[0]
+    Ao, Mo = orc.csc_operator(A), orc.jacobi_operator(A.diagonal())
+    rng = np.random.default_rng(2)
+    b = rng.standard_normal(n)
+    x0 = np.zeros(n)
+    xc, itc, resc = orc.cg(Ao, b, x0)
+    xe, ite, rese, V = orc.eigcg(Ao, b, x0, 6, 20)
+    assert abs(ite - itc) <= 1 and np.allclose(rese[:20], resc[:20], rtol=1e-10)
+    lam = np.linalg.eigvalsh(A.toarray())[:6]
+    rq = np.sort([V[:, j] @ (A @ V[:, j]) / (V[:, j] @ V[:, j]) for j in range(6)])
+    assert abs(rq[0] - lam[0]) <= 1e-5 * lam[0] and np.allclose(rq[:3], lam[:3], rtol=3e-2)   # lowest pairs converge first
+    assert np.all(rq >= lam * (1 - 1e-10))                  # Ritz values approach from above (interlacing)
+    xp, itp, resp = orc.pcg(Ao, b, x0, Mo)
+    xq, itq, resq, Vp = orc.eigpcg(Ao, b, x0, Mo, 6, 20)
+    assert abs(itq - itp) <= 1 and np.allclose(resq[:20], resp[:20], rtol=1e-10)
+    b2 = rng.standard_normal(n)
+    it_plain = orc.pcg(Ao, b2, x0, Mo)[1]
+    xd, itd, resd, V2 = orc.eigdefpcg(Ao, b2, x0, Mo, Vp, 20)
+    assert itd < it_plain and np.linalg.norm(b2 - A @ xd) <= 2e-7 * np.linalg.norm(b2)
+    assert orc.defpcg(Ao, b2, x0, Vp, Mo)[1] in (itd - 1, itd, itd + 1)
+    xd, itd2, _, V3 = orc.eigdefcg(Ao, b2, x0, V, 20)
+    assert itd2 < orc.cg(Ao, b2, x0)[1]
+    xi, iti, resi = orc.initcg(Ao, b2, x0, V)
+    assert iti <= orc.cg(Ao, b2, x0)[1] and np.linalg.norm(b2 - A @ xi) <= 2e-7 * np.linalg.norm(b2)
+    with pytest.raises(orc.BoundsError):
+        orc.eigcg(Ao, b, x0, 6, 12)                        # spdim < 2 nvec + 1
+
+
+def test_host_dense_kernels_of_the_eig_restart(tmp_path):
+    """csrc/dense_small.hpp (Jacobi eigen / one-sided Jacobi SVD / the Ritz restart block) compiled for the host."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "dense_small_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "dense_small_check.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout

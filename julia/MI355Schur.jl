@@ -16,17 +16,19 @@ import LinearAlgebra: mul!, ldiv!
 export MiContext, MiOperator, MiPrecond,
        LocalSchurs, MatrixFreeLocalSchurs, GlobalSchur, NeumannNeumannSchurPreconditioner,
        apply_local_schurs, apply_global_schur, apply_neumann_neumann_schur,
-       cg, pcg, defcg, defpcg
+       cg, pcg, defcg, defpcg, eigcg, eigpcg, eigdefcg, eigdefpcg, initcg, initpcg
 
 const lib = get(ENV, "MI355SCHUR_LIB", "libmi355schur")
 const MI_ERR_SINGULAR = Cint(-3)
 const MI_ERR_RES_CAPACITY = Cint(-4)
+const MI_ERR_BOUNDS = Cint(-8)
 
 function check(rc::Cint)
   rc == 0 && return
   msg = unsafe_string(ccall((:mi_last_error, lib), Cstring, ()))
   rc == MI_ERR_SINGULAR && throw(LinearAlgebra.SingularException(0))   # `WtAW \ mu`, defcg.jl:53,273
   rc == MI_ERR_RES_CAPACITY && throw(BoundsError())                    # res_norm[it], cg.jl:47
+  rc == MI_ERR_BOUNDS && throw(BoundsError())                          # V[:, nev+1] / eigvecs(...)[:, 1:nvec], eigcg.jl:101,275
   error("libmi355schur error $rc: $msg")
 end
 
@@ -228,5 +230,54 @@ cg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}; maxit=0) = solve(:cg, 
 pcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, M::MiOperator; maxit=0) = solve(:pcg, A, M, b, x, nothing, maxit)
 defcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, W::Matrix{Float64}; maxit=0) = solve(:defcg, A, nothing, b, x, W, maxit)
 defpcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, W::Matrix{Float64}, M::MiOperator; maxit=0) = solve(:defpcg, A, M, b, x, W, maxit)
+
+# eigCG family and Init-CG (eigcg.jl:27-33, 143-150; defcg.jl:111-116, 337-343; initcg.jl:28-33, 106-111).
+# Same positional orders and 4-tuple / 3-tuple returns as the reference (Example09_..._Functions.jl:314, 364).
+function eigsolve(kind::Symbol, A::MiOperator, M, b::Vector{Float64}, x::Vector{Float64}, W, nvec::Int, spdim::Int, maxit::Int)
+  n = A.n
+  res = Vector{Float64}(undef, n); it = Ref{Int64}(0)
+  V = Matrix{Float64}(undef, n, nvec)
+  tail = (Int64(spdim), Int64(maxit), 1e-7, res, Int64(n), it, V)
+  rc = if kind == :eigcg
+    ccall((:mi_eigcg, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Float64, Ptr{Float64}, Int64, Ref{Int64}, Ptr{Float64}),
+          A.h, b, x, Int64(nvec), tail...)
+  elseif kind == :eigpcg
+    ccall((:mi_eigpcg, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Float64, Ptr{Float64}, Int64, Ref{Int64}, Ptr{Float64}),
+          A.h, M.h, b, x, Int64(nvec), tail...)
+  elseif kind == :eigdefcg
+    ccall((:mi_eigdefcg, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Float64, Ptr{Float64}, Int64, Ref{Int64}, Ptr{Float64}),
+          A.h, b, x, W, Int64(nvec), tail...)
+  else
+    ccall((:mi_eigdefpcg, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Float64, Ptr{Float64}, Int64, Ref{Int64}, Ptr{Float64}),
+          A.h, M.h, b, x, W, Int64(nvec), tail...)
+  end
+  check(rc)
+  return x, Int(it[]), res[1:it[]], V
+end
+
+eigcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, nvec::Int, spdim::Int; maxit=0) =
+  eigsolve(:eigcg, A, nothing, b, x, nothing, nvec, spdim, maxit)
+eigpcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, M::MiOperator, nvec::Int, spdim::Int; maxit=0) =
+  eigsolve(:eigpcg, A, M, b, x, nothing, nvec, spdim, maxit)
+eigdefcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, W::Matrix{Float64}, spdim::Int; maxit=0) =
+  eigsolve(:eigdefcg, A, nothing, b, x, W, size(W, 2), spdim, maxit)
+eigdefpcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, M::MiOperator, W::Matrix{Float64}, spdim::Int; maxit=0) =
+  eigsolve(:eigdefpcg, A, M, b, x, W, size(W, 2), spdim, maxit)
+
+function initsolve(A::MiOperator, M, b::Vector{Float64}, x::Vector{Float64}, W::Matrix{Float64}, maxit::Int)
+  n = A.n
+  res = Vector{Float64}(undef, n); it = Ref{Int64}(0)
+  rc = if M === nothing
+    ccall((:mi_initcg, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Float64, Ptr{Float64}, Int64, Ref{Int64}),
+          A.h, b, x, W, size(W, 2), maxit, 1e-7, res, n, it)
+  else
+    ccall((:mi_initpcg, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Float64, Ptr{Float64}, Int64, Ref{Int64}),
+          A.h, M.h, b, x, W, size(W, 2), maxit, 1e-7, res, n, it)
+  end
+  check(rc)
+  return x, Int(it[]), res[1:it[]]
+end
+initcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, W::Matrix{Float64}; maxit=0) = initsolve(A, nothing, b, x, W, maxit)
+initpcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, M::MiOperator, W::Matrix{Float64}; maxit=0) = initsolve(A, M, b, x, W, maxit)
 
 end # module

@@ -50,6 +50,16 @@ W = np.asfortranarray(np.linalg.eigh(Sd)[1][:, :P.sub.ndom + 10])
 Wd = torch.from_numpy(np.ascontiguousarray(W.T)).cuda().T
 it, dt = rate(lambda: api.defpcg(S, bd, torch.zeros_like(bd), Wd, M)[1], 50)
 print(f"defpcg nvec={W.shape[1]}      : it={it} {dt * 1e6:8.1f} us/solve {(it - 1) / dt:9.0f} it/s")
+nvec, spdim = int(1.25 * P.sub.ndom), 3 * P.sub.ndom            # Example09:39-40
+it, dt = rate(lambda: api.eigpcg(S, bd, torch.zeros_like(bd), M, nvec, spdim)[1], 50)
+print(f"eigpcg nvec={nvec} spdim={spdim}: it={it} {dt * 1e6:8.1f} us/solve {(it - 1) / dt:9.0f} it/s")
+We = api.eigpcg(S, bd, torch.zeros_like(bd), M, nvec, spdim)[3]
+it, dt = rate(lambda: api.eigdefpcg(S, bd, torch.zeros_like(bd), M, We, spdim)[1], 50)
+print(f"eigdefpcg nvec={nvec}       : it={it} {dt * 1e6:8.1f} us/solve {(it - 1) / dt:9.0f} it/s")
+it, dt = rate(lambda: api.eigcg(S, bd, torch.zeros_like(bd), nvec, spdim)[1], 10)
+print(f"eigcg (no precond)  : it={it} {dt * 1e6:8.1f} us/solve {(it - 1) / dt:9.0f} it/s")
+if os.environ.get("MEASURE_SKIP_MATFREE"):
+    sys.exit(0)
 Sm = api.MatrixFreeLocalSchurs(ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, P.sub.node_Γ_cnt, P.solvers)
 Sm * b
 t0 = time.perf_counter(); Sm * b; t1 = time.perf_counter()

@@ -275,7 +275,7 @@ struct LocalMaps {
 struct DenseBlockOp : Operator {
   LocalMaps maps;
   bool scale;  // true: Neumann-Neumann (gather r/cnt, result /cnt)
-  int rpw, waves, ntiles = 0, max_nd = 0;  // rows per wave, waves per workgroup (4, 8 or 16)
+  int rpw, waves, ntiles = 0, max_nd = 0, max_ld = 0;  // rows per wave, waves per workgroup (4, 8 or 16)
   bool reduce_over_ranks = false;          // this rank holds only a slice of the subdomains and a communicator exists
   DevBuf<double> M, cnt, yslots;
   DevBuf<double> yslots_all;  // multi-GPU: all-reduced copy of the contribution slots (every rank's subdomains)
@@ -302,10 +302,15 @@ struct DenseBlockOp : Operator {
     std::vector<GemvTile> tv;
     long long tot = 0;
     for (int dl = 0; dl < maps.ndl; ++dl) {
-      const int n_d = maps.nd[dl], l = (n_d + 15) / 16 * 16;
+      const int n_d = maps.nd[dl];
+      int l = (n_d + 15) / 16 * 16;
+      // A row stride that is a multiple of 2 KiB puts every row of a tile on the same HBM channels: measured 27 % slower
+      // at n_Γd = 1024 (profiles/r01_gemv_variant_sweep.txt). One extra 128-byte line per row breaks the pattern.
+      if (l % 256 == 0 && l != GEMV_PANEL) l += 16;
       if (n_d && !blocks[d0 + dl]) raise(MI_ERR_BAD_ARG, "dense block %d is NULL", dl);
       moff.push_back(tot); ldv.push_back(l);
       max_nd = std::max(max_nd, n_d);
+      max_ld = std::max(max_ld, l);
       for (int r = 0; r < n_d; r += waves * rpw) tv.push_back(GemvTile{tot, n_d, l, maps.loc_off[dl], r, 0, 0});
       tot += (long long)n_d * l;
       alg_bytes += 8ll * n_d * n_d + 16ll * n_d + 4ll * n_d;
@@ -367,7 +372,7 @@ struct DenseBlockOp : Operator {
     if (!ntiles) return;
 #define MI_PCG3(R, C, V) do { if (phase) hipLaunchKernelGGL((k_gemv_pcg<R, 1, C, V>), dim3(ntiles), dim3(64 * V), 0, ctx->stream, meta, f); \
                               else hipLaunchKernelGGL((k_gemv_pcg<R, 0, C, V>), dim3(ntiles), dim3(64 * V), 0, ctx->stream, meta, f); } while (0)
-#define MI_PCG2(R, V) do { const int c = (max_nd + 64 * V - 1) / (64 * V); \
+#define MI_PCG2(R, V) do { const int c = (max_ld + 64 * V - 1) / (64 * V); \
                            if (c <= 2) MI_PCG3(R, 2, V); else if (c == 3) MI_PCG3(R, 3, V); else if (c == 4) MI_PCG3(R, 4, V); \
                            else if (c == 5) MI_PCG3(R, 5, V); else if (c == 6) MI_PCG3(R, 6, V); else MI_PCG3(R, 8, V); } while (0)
 #define MI_PCG(R) do { if (waves == 16) MI_PCG2(R, 16); else if (waves == 8) MI_PCG2(R, 8); else MI_PCG2(R, 4); } while (0)

@@ -179,8 +179,8 @@ struct Krylov {
     if (fused && M && nvec == 0 && !env_int("MI355_NO_FOLD", 0)) {
       Ad = A->as_dense(); Md = M->as_dense();
       fold = Ad && Md && !Ad->reduce_over_ranks && !Md->reduce_over_ranks &&
-             !Ad->scale && Md->scale && Ad->same_maps(*Md) && Ad->ntiles > 0 && Ad->max_nd <= GEMV_PANEL && Ad->maps.slot_width <= 4 &&
-             (Ad->max_nd + 64 * Ad->waves - 1) / (64 * Ad->waves) <= 8;
+             !Ad->scale && Md->scale && Ad->same_maps(*Md) && Ad->ntiles > 0 && Ad->max_ld <= GEMV_PANEL && Ad->maps.slot_width <= 4 &&
+             (Ad->max_ld + 64 * Ad->waves - 1) / (64 * Ad->waves) <= 8;
     }
   }
   PcgFold fold_args(int phase) const {

@@ -49,6 +49,7 @@ extern "C" {
 typedef struct mi_ctx_s *mi_ctx_t; /* device + stream + workspaces (+ RCCL communicator)            */
 typedef struct mi_op_s *mi_op_t;   /* anything usable as `A` (A*x, mul!) or as `M` (M \ r)          */
 typedef struct mi_event_s *mi_event_t;
+typedef struct mi_plan_s *mi_plan_t; /* index half of prepare_local_schurs for a fixed mesh / partition          */
 
 /* Interior solve callback: sol = A_II[idom]^{-1} rhs on HOST memory, called from the calling
  * thread only (Julia @cfunction safe). Replaces `IterativeSolvers.cg(A_IIdd, rhs; Pl, reltol)`
@@ -190,6 +191,32 @@ int mi_defcg(mi_op_t A, const double *b, double *x, const double *W, int64_t nve
              double eps, double *res_norm, int64_t res_cap, int64_t *it);
 int mi_defpcg(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec,
               int64_t maxit, double eps, double *res_norm, int64_t res_cap, int64_t *it);
+
+/* ---------------------------------------------------------------- on-device block assembly (per-realization update)
+ * Replaces the element loop of `prepare_local_schurs(cells, points, epart, ..., coeff, f, uexact)`
+ * (EPDD.jl:389-546) when only the nodal coefficient vector `a` changes between calls — Example07:162-171 redoes the
+ * whole loop on the host for every realization. The caller prepares the index half once:
+ *   cells  3 x nel node indices (row i contiguous: vertex i of every element), `index_base` 0 or 1
+ *   G      9 x nel, G[3i+j] = Δy_i Δy_j + Δx_i Δx_j (:448-453, 470);  area  nel (:456)
+ *   ue     3 x nel, uexact at vertex i (Dirichlet lifting, :498-507); be  3 x nel, Δb_i = (2f_i+f_j+f_k) Area/12 (:516-525)
+ *   cptr / ccode: entry k of the output is the sum, IN ORDER, of the contributions ccode[cptr[k] .. cptr[k+1]), each
+ *   coded 12*element + 3i + j (ΔK_ij = Δa G_ij/4/Area with Δa = (a_1+a_2+a_3)/3; for k >= n_matrix_entries the
+ *   lifting term -(ΔK_ij ue_i)) or 12*element + 9 + i (Δb_i); 0-based. The order inside an entry is the order in which
+ *   `sparse(I,J,V)` / `b[k] +=` met the terms (ascending element), so results are bit-identical to the host loop.
+ * mi_assembly_run: a_nodal (n_node) -> values (n_entries); host or device pointers per the context's pointer mode
+ *   (device pointers: asynchronous on the context's stream, like mi_op_apply).
+ * mi_schur_matfree_set_values: new block values for a matrix-free operator, same sparsity as at create; each array is
+ *   the concatenation over the operator's subdomains [dom_begin, dom_end) of the arrays passed at create (A_IIdd: its
+ *   CSC/CSR values; A_IΓdd: CSC values; A_ΓΓdd); NULL leaves a block unchanged; ii_val needs the device interior solve.
+ * mi_schur_matfree_rhs: `get_schur_rhs` (EPDD.jl:835-864): b_schur = b_Γ - Σ_d R_d' A_IΓdd' (A_IIdd \ b_Id) with the
+ *   operator's own interior solve; b_I is the concatenation of the b_Id. Collective on a sharded operator. */
+int mi_assembly_plan_create(mi_ctx_t ctx, int64_t nel, int64_t n_node, const int64_t *cells, int index_base,
+                            const double *G, const double *area, const double *ue, const double *be, int64_t n_entries,
+                            int64_t n_matrix_entries, const int64_t *cptr, const int64_t *ccode, mi_plan_t *plan);
+int mi_assembly_run(mi_plan_t plan, const double *a_nodal, double *values);
+int mi_assembly_plan_destroy(mi_plan_t plan);
+int mi_schur_matfree_set_values(mi_op_t op, const double *ii_val, const double *ig_val, const double *gg_val);
+int mi_schur_matfree_rhs(mi_op_t op, const double *b_I, const double *b_gamma, double *b_schur);
 
 /* ---------------------------------------------------------------- eigCG family and Init-CG (recycling solvers)
  * Reference signatures (RecyclingKrylovSolvers/eigcg.jl:27-33, 143-150; defcg.jl:111-116, 337-343; initcg.jl:28-33,

@@ -67,6 +67,11 @@ SIGNATURES = {
     "mi_pcg": [vp, vp, vp, vp, i64, C.c_double, f64p, i64, i64p],
     "mi_defcg": [vp, vp, vp, vp, i64, i64, C.c_double, f64p, i64, i64p],
     "mi_defpcg": [vp, vp, vp, vp, vp, i64, i64, C.c_double, f64p, i64, i64p],
+    "mi_assembly_plan_create": [vp, i64, i64, i64p, C.c_int, f64p, f64p, f64p, f64p, i64, i64, i64p, i64p, C.POINTER(vp)],
+    "mi_assembly_run": [vp, vp, vp],
+    "mi_assembly_plan_destroy": [vp],
+    "mi_schur_matfree_set_values": [vp, vp, vp, vp],
+    "mi_schur_matfree_rhs": [vp, vp, vp, vp],
     "mi_eigcg": [vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],
     "mi_eigpcg": [vp, vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],
     "mi_eigdefcg": [vp, vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],

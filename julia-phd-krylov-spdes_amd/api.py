@@ -398,6 +398,85 @@ class MatrixFreeLocalSchurs(Operator):
             cb, None, C.c_int(0), i64(lo), i64(hi), C.byref(h)))
         super().__init__(ctx, h, keep=(cb, interior_solvers))
 
+    def set_values(self, ii_val=None, ig_val=None, gg_val=None) -> None:
+        """New block values on the patterns given at construction (Example07:162-171 without re-creating the operator).
+        Each argument: the concatenation over this operator's subdomains of the blocks' CSC `nzval` — the layout of
+        `AssemblyPlan.run` / `fem.AssemblyPlan.layout` — as numpy arrays or torch CUDA tensors; None = unchanged."""
+        self.ctx._mode_for(ii_val, ig_val, gg_val)
+        k1, p1 = self.ctx._ptr(ii_val)
+        k2, p2 = self.ctx._ptr(ig_val)
+        k3, p3 = self.ctx._ptr(gg_val)
+        check(self.ctx._L.mi_schur_matfree_set_values(self._h, p1, p2, p3))
+
+    def schur_rhs(self, b_I, b_Γ):
+        """`get_schur_rhs(b_Id, A_IIdd, A_IΓdd, b_Γ, ind_Γd_Γ2l; preconds)` (EPDD.jl:835-864) with this operator's
+        interior solve; `b_I` is the concatenation of the b_Id of this operator's subdomains."""
+        self.ctx._mode_for(b_I, b_Γ)
+        k1, p1 = self.ctx._ptr(b_I)
+        k2, p2 = self.ctx._ptr(b_Γ, self.n)
+        if _is_torch(b_Γ):
+            import torch
+            out = torch.empty_like(b_Γ)
+            po = vp(out.data_ptr())
+        else:
+            out = np.empty(self.n)
+            po = vp(out.ctypes.data)
+        check(self.ctx._L.mi_schur_matfree_rhs(self._h, p1, p2, po))
+        return out
+
+
+class AssemblyPlan:
+    """Device executor of a `fem.AssemblyPlan` (`mi_plan_t`): `run(a)` is the numeric half of
+    `prepare_local_schurs(cells, points, epart, ..., a, f, uexact)` (EPDD.jl:389-546) for a new coefficient vector."""
+
+    def __init__(self, ctx: Context, plan):
+        self.ctx, self.plan = ctx, plan
+        h = vp()
+        cells = _i64(plan.cells)
+        arrs = [_f64(plan.G), _f64(plan.area), _f64(plan.ue), _f64(plan.be)]
+        cptr, ccode = _i64(plan.cptr), _i64(plan.ccode)
+        check(ctx._L.mi_assembly_plan_create(
+            ctx._h, i64(cells.shape[1]), i64(plan.n_node), cells.ctypes.data_as(i64p), C.c_int(0),
+            *[a.ctypes.data_as(f64p) for a in arrs], i64(plan.n_entries), i64(plan.n_matrix_entries),
+            cptr.ctypes.data_as(i64p), ccode.ctypes.data_as(i64p), C.byref(h)))
+        self._h = h
+
+    def run(self, a_nodal):
+        """values[n_entries]: numpy in -> numpy out; torch CUDA tensor in -> torch CUDA tensor out (stays on the device)."""
+        self.ctx._mode_for(a_nodal)
+        ka, pa = self.ctx._ptr(a_nodal, self.plan.n_node)
+        if _is_torch(a_nodal):
+            import torch
+            out = torch.empty(self.plan.n_entries, dtype=torch.float64, device=a_nodal.device)
+            po = vp(out.data_ptr())
+        else:
+            out = np.empty(self.plan.n_entries)
+            po = vp(out.ctypes.data)
+        check(self.ctx._L.mi_assembly_run(self._h, pa, po))
+        return out
+
+    def block_values(self, values, lo: int = 0, hi: Optional[int] = None):
+        """(ii_val, ig_val, gg_val, b_I, b_Γ) slices of `values` for subdomains lo..hi-1: contiguous views, ready for
+        `MatrixFreeLocalSchurs.set_values` / `.schur_rhs`."""
+        L = self.plan.layout
+        hi = len(L["II"]) if hi is None else hi
+
+        def span(name):
+            return values[L[name][lo][0]:L[name][hi - 1][0] + L[name][hi - 1][1]]
+        off, cnt = L["bΓ"]
+        return span("II"), span("IΓ"), span("ΓΓ"), span("bI"), values[off:off + cnt]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self.ctx._L.mi_assembly_plan_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 class GlobalSchur(Operator):
     """`x -> apply_global_schur(A_IId, A_IΓd, A_ΓΓ, x; preconds)` (EPDD.jl:596-625), the closure of Example03:101."""

@@ -561,6 +561,105 @@ int mi_initpcg(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W
   return run_init_solver(A, M, b, x, W, nvec, maxit, eps, res_norm, res_cap, it, true);
 }
 
+// ---------------------------------------------------------------- on-device block assembly
+int mi_assembly_plan_create(mi_ctx_t ctx, int64_t nel, int64_t n_node, const int64_t *cells, int index_base, const double *G,
+                            const double *area, const double *ue, const double *be, int64_t n_entries,
+                            int64_t n_matrix_entries, const int64_t *cptr, const int64_t *ccode, mi_plan_t *plan) {
+  if (!plan) return fail(MI_ERR_BAD_ARG, "plan is NULL");
+  *plan = nullptr;
+  if (!ctx || nel < 0 || n_node < 0 || n_entries < 0 || n_matrix_entries < 0 || n_matrix_entries > n_entries || !cptr ||
+      (nel && (!cells || !G || !area || !ue || !be)) || (index_base != 0 && index_base != 1))
+    return fail(MI_ERR_BAD_ARG, "mi_assembly_plan_create: bad argument");
+  if (12 * nel >= INT32_MAX) return fail(MI_ERR_BAD_ARG, "mi_assembly_plan_create: 12*nel must fit 32 bits");
+  return guarded([&]() -> int {
+    ctx->use();
+    const int64_t nc = cptr[n_entries];
+    if (cptr[0] != 0 || nc < 0 || (nc && !ccode)) return fail(MI_ERR_BAD_ARG, "mi_assembly_plan_create: bad cptr / ccode");
+    std::vector<long long> cp((size_t)n_entries + 1);
+    for (int64_t k = 0; k <= n_entries; ++k) {
+      if (cptr[k] < 0 || cptr[k] > nc || (k && cptr[k] < cptr[k - 1])) return fail(MI_ERR_BAD_ARG, "cptr is not monotone");
+      cp[k] = cptr[k];
+    }
+    std::vector<int> cc((size_t)nc), cl((size_t)3 * nel);
+    for (int64_t c = 0; c < nc; ++c) {
+      if (ccode[c] < 0 || ccode[c] >= 12 * nel) return fail(MI_ERR_BAD_ARG, "contribution code %lld out of range", (long long)ccode[c]);
+      cc[c] = (int)ccode[c];
+    }
+    for (int64_t k = 0; k < 3 * nel; ++k) cl[k] = to_i32(cells[k] - index_base, 0, n_node, "cells");
+    std::unique_ptr<mi_plan_s> p(new mi_plan_s);
+    p->ctx = ctx; p->nel = (int)nel; p->n_node = n_node; p->n_entries = n_entries; p->n_matrix = n_matrix_entries; p->n_contrib = nc;
+    hipStream_t s = ctx->stream;
+    p->cells.upload(cl, s); p->ccode.upload(cc, s); p->cptr.upload(cp, s);
+    p->G.upload(G, (size_t)9 * nel, s); p->area.upload(area, (size_t)nel, s);
+    p->ue.upload(ue, (size_t)3 * nel, s); p->be.upload(be, (size_t)3 * nel, s);
+    p->da.alloc((size_t)nel + 1);
+    MI_HIP(hipStreamSynchronize(s));
+    *plan = p.release();
+    return MI_OK;
+  });
+}
+int mi_assembly_run(mi_plan_t plan, const double *a_nodal, double *values) {
+  if (!plan || !a_nodal || (plan->n_entries && !values)) return fail(MI_ERR_BAD_ARG, "mi_assembly_run: NULL argument");
+  mi_ctx_s *c = plan->ctx;
+  return guarded([&]() -> int {
+    c->use();
+    In ai(c, a_nodal, (size_t)plan->n_node, plan->a_stage);
+    InOut vo(c, values, (size_t)plan->n_entries, plan->out_stage, false);
+    auto grid = [](int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + NT - 1) / NT, 1 << 20)); };
+    if (plan->nel)
+      hipLaunchKernelGGL(k_elem_coeff, dim3(grid(plan->nel)), dim3(NT), 0, c->stream, plan->nel, plan->cells.p, ai.dev, plan->da.p);
+    if (plan->n_entries)
+      hipLaunchKernelGGL(k_assemble_plan, dim3(grid(plan->n_entries)), dim3(NT), 0, c->stream, (long long)plan->n_entries,
+                         (long long)plan->n_matrix, plan->nel, plan->cptr.p, plan->ccode.p, plan->da.p, plan->G.p, plan->area.p,
+                         plan->ue.p, plan->be.p, vo.dev);
+    MI_HIP(hipGetLastError());
+    vo.finish();
+    return MI_OK;
+  });
+}
+int mi_assembly_plan_destroy(mi_plan_t plan) {
+  if (!plan) return MI_OK;
+  return guarded([&]() -> int {
+    plan->ctx->use();
+    (void)hipStreamSynchronize(plan->ctx->stream);
+    delete plan;
+    return MI_OK;
+  });
+}
+static MatfreeSchurOp *as_matfree(mi_op_t op) {
+  return op && op->impl ? dynamic_cast<MatfreeSchurOp *>(op->impl.get()) : nullptr;
+}
+int mi_schur_matfree_set_values(mi_op_t op, const double *ii_val, const double *ig_val, const double *gg_val) {
+  MatfreeSchurOp *m = as_matfree(op);
+  if (!m) return fail(MI_ERR_BAD_ARG, "mi_schur_matfree_set_values: not a matrix-free local-Schur operator");
+  mi_ctx_s *c = m->ctx;
+  return guarded([&]() -> int {
+    c->use();
+    DevBuf<double> s1, s2, s3;
+    In a(c, ii_val, ii_val && m->icg ? (size_t)m->icg->A.nnz : 0, s1), b(c, ig_val, ig_val ? (size_t)m->A_GI.nnz : 0, s2),
+        g(c, gg_val, gg_val ? (size_t)m->A_GG.nnz : 0, s3);
+    m->set_values(ii_val ? a.dev : nullptr, ig_val ? b.dev : nullptr, gg_val ? g.dev : nullptr);
+    MI_HIP(hipStreamSynchronize(c->stream));  // staging buffers go out of scope
+    return MI_OK;
+  });
+}
+int mi_schur_matfree_rhs(mi_op_t op, const double *b_I, const double *b_gamma, double *b_schur) {
+  MatfreeSchurOp *m = as_matfree(op);
+  if (!m || !b_gamma || !b_schur || (m->ni_tot && !b_I))
+    return fail(MI_ERR_BAD_ARG, "mi_schur_matfree_rhs: not a matrix-free local-Schur operator, or NULL argument");
+  mi_ctx_s *c = m->ctx;
+  return guarded([&]() -> int {
+    c->use();
+    DevBuf<double> s1;
+    In bi(c, b_I, (size_t)m->ni_tot, s1), bg(c, b_gamma, (size_t)m->n, c->scratch_a);
+    InOut out(c, b_schur, (size_t)m->n, c->scratch_b, false);
+    m->schur_rhs(bi.dev, bg.dev, out.dev);
+    out.finish();
+    MI_HIP(hipStreamSynchronize(c->stream));
+    return MI_OK;
+  });
+}
+
 // ---------------------------------------------------------------- events
 int mi_event_create(mi_event_t *ev) {
   if (!ev) return fail(MI_ERR_BAD_ARG, "ev is NULL");

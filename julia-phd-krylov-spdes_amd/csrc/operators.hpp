@@ -6,6 +6,7 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "assembly.hpp"
 
 namespace mi {
 
@@ -516,7 +517,8 @@ struct MatfreeSchurOp : Operator {
   int ni_tot = 0;
   mi_interior_solve_fn solve; void *user;
   std::unique_ptr<InteriorCg> icg;
-  DevBuf<double> xcat, rhs, sol, t1, yloc;
+  DevBuf<double> xcat, rhs, sol, t1, yloc, t2;
+  DevBuf<int> ig_perm;  // A_IG.val[k] = (caller's concatenated A_IΓ values)[ig_perm[k]]  (set_values)
   HostStage stage;
 
   MatfreeSchurOp(mi_ctx_s *c, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d, const int64_t *n_i,
@@ -531,6 +533,7 @@ struct MatfreeSchurOp : Operator {
     if (ii_ptr && (!ii_idx || !ii_val || !(reltol > 0.0))) raise(MI_ERR_BAD_ARG, "device interior: bad A_II arrays / reltol");
     maps.build(c, ndom, n_gamma, n_gamma_d, gather_idx, base, d0, d1);
     HostCsr ig, gi, gg, ii;
+    std::vector<int> perm_h;
     int64_t itot = 0;
     for (int dl = 0; dl < maps.ndl; ++dl) { ioff.push_back((int)itot); ni.push_back((int)n_i[d0 + dl]); itot += n_i[d0 + dl]; }
     if (itot >= INT32_MAX) raise(MI_ERR_BAD_ARG, "interior too large");
@@ -540,6 +543,12 @@ struct MatfreeSchurOp : Operator {
       // CSC arrays of A_IΓdd (n_i x n_Γd) are the CSR arrays of A_ΓIdd = A_IΓdd' (n_Γd x n_i)
       HostCsr gi_d = host_csr(maps.nd[dl], ni[dl], ig_ptr[d], ig_idx[d], ig_val[d], base);
       HostCsr ig_d = transpose(gi_d);
+      {  // where every entry of the transpose came from, in the caller's concatenated value order
+        HostCsr tag = gi_d;
+        for (size_t k = 0; k < tag.val.size(); ++k) tag.val[k] = (double)(gi.val.size() + k);
+        const HostCsr t = transpose(tag);
+        for (double v : t.val) perm_h.push_back((int)v);
+      }
       HostCsr gg_d = host_csr(maps.nd[dl], maps.nd[dl], gg_ptr[d], gg_idx[d], gg_val[d], base);
       append_block(gi, gi_d, ioff[dl], ni_tot);
       append_block(ig, ig_d, maps.loc_off[dl], maps.nloc);
@@ -548,8 +557,9 @@ struct MatfreeSchurOp : Operator {
     }
     if (gi.rowptr.empty()) { gi.rowptr = {0}; ig.rowptr = {0}; gg.rowptr = {0}; ii.rowptr = {0}; }
     A_IG.upload(ig, c->stream); A_GI.upload(gi, c->stream); A_GG.upload(gg, c->stream);
+    ig_perm.upload(perm_h, c->stream);
     xcat.alloc(maps.nloc + 1); t1.alloc(maps.nloc + 1); yloc.alloc(maps.nloc + 1);
-    rhs.alloc(ni_tot + 1); sol.alloc(ni_tot + 1);
+    rhs.alloc(ni_tot + 1); sol.alloc(ni_tot + 1); t2.alloc((size_t)n_gamma + 1);
     if (ii_ptr) {
       icg.reset(new InteriorCg);
       icg->build(c, ii, ioff, ni, reltol);
@@ -578,6 +588,41 @@ struct MatfreeSchurOp : Operator {
       A_GI.launch(1, sol.p, t1.p, yloc.p, nullptr, s);
     }
     maps.assemble(ctx, n, yloc.p, y, nullptr);
+  }
+  // New block values on the same patterns (device pointers; each array is the concatenation over this operator's
+  // subdomains of what was passed at create): the per-realization update of Example07:162-171 without a host trip.
+  void set_values(const double *ii_val, const double *ig_val, const double *gg_val) {
+    hipStream_t s = ctx->stream;
+    if (ii_val) {
+      if (!icg) raise(MI_ERR_BAD_ARG, "set_values: A_II lives in the interior-solve callback of this operator");
+      if (icg->A.nnz) MI_HIP(hipMemcpyAsync(icg->A.val.p, ii_val, sizeof(double) * icg->A.nnz, hipMemcpyDeviceToDevice, s));
+    }
+    if (ig_val && A_GI.nnz) {
+      MI_HIP(hipMemcpyAsync(A_GI.val.p, ig_val, sizeof(double) * A_GI.nnz, hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(k_permute, dim3(vec_grid(A_IG.nnz)), dim3(NT), 0, s, (long long)A_IG.nnz, ig_perm.p, ig_val, A_IG.val.p);
+      MI_HIP(hipGetLastError());
+    }
+    if (gg_val && A_GG.nnz) MI_HIP(hipMemcpyAsync(A_GG.val.p, gg_val, sizeof(double) * A_GG.nnz, hipMemcpyDeviceToDevice, s));
+  }
+  // b_schur = b_Γ - Σ_d R_d' A_IΓdd' (A_IIdd^{-1} b_Id)   (get_schur_rhs, EPDD.jl:835-864); b_I: concatenated b_Id
+  void schur_rhs(const double *b_I, const double *b_gamma, double *out) {
+    hipStream_t s = ctx->stream;
+    if (maps.nloc) {
+      if (icg) {
+        icg->solve(b_I, sol.p);
+      } else {
+        MI_HIP(hipMemcpyAsync(stage.rhs, b_I, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+        for (int dl = 0; dl < maps.ndl; ++dl)
+          if (solve(user, d0 + dl, ni[dl], stage.rhs + ioff[dl], stage.sol + ioff[dl]) != 0)
+            raise(MI_ERR_CALLBACK, "interior solve callback failed on subdomain %lld", (long long)(d0 + dl));
+        MI_HIP(hipMemcpyAsync(sol.p, stage.sol, sizeof(double) * ni_tot, hipMemcpyHostToDevice, s));
+      }
+      A_GI.launch(0, sol.p, nullptr, yloc.p, nullptr, s);
+    }
+    maps.assemble(ctx, n, yloc.p, t2.p, nullptr);
+    hipLaunchKernelGGL(k_sub, dim3(vec_grid(n)), dim3(NT), 0, s, (int)n, b_gamma, t2.p, out);
+    MI_HIP(hipGetLastError());
   }
   void bytes(int64_t *a, int64_t *d) const override {
     *a = A_IG.bytes() + A_GI.bytes() + A_GG.bytes() + 16ll * ni_tot;

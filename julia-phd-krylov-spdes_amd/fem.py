@@ -264,13 +264,11 @@ def _element_terms(cells, points, coeff: Coeff, f, uexact):
     for j in range(3):
         Δa = Δa + a[j]
     Δa = Δa / 3.0
-    Δx = np.stack([x[2] - x[1], x[0] - x[2], x[1] - x[0]])
-    Δy = np.stack([y[1] - y[2], y[2] - y[0], y[0] - y[1]])
-    Area = (Δx[2] * Δy[1] - Δx[1] * Δy[2]) / 2.0
+    G, Area = _element_geometry(x, y)
     K = np.empty((3, 3, cells.shape[1]))
     for i in range(3):
         for j in range(3):
-            K[i, j] = Δa * (Δy[i] * Δy[j] + Δx[i] * Δx[j]) / 4 / Area
+            K[i, j] = Δa * G[i, j] / 4 / Area
     fv = _eval(f, x, y)
     b = np.empty((3, cells.shape[1]))
     for i in range(3):
@@ -278,6 +276,31 @@ def _element_terms(cells, points, coeff: Coeff, f, uexact):
         b[i] = (2 * fv[i] + fv[j] + fv[k]) * Area / 12
     ue = _eval(uexact, x, y)
     return K, b, ue
+
+
+def _element_geometry(x, y):
+    """Shoelace terms (EPDD.jl:272-277), G_ij = Δy_i*Δy_j + Δx_i*Δx_j (the coefficient-free factor of ΔK_ij) and Area (:280)."""
+    Δx = np.stack([x[2] - x[1], x[0] - x[2], x[1] - x[0]])
+    Δy = np.stack([y[1] - y[2], y[2] - y[0], y[0] - y[1]])
+    Area = (Δx[2] * Δy[1] - Δx[1] * Δy[2]) / 2.0
+    G = np.empty((3, 3, x.shape[1]))
+    for i in range(3):
+        for j in range(3):
+            G[i, j] = Δy[i] * Δy[j] + Δx[i] * Δx[j]
+    return G, Area
+
+
+def _segment_sums(v, starts):
+    """Sum of every segment v[starts[k]:starts[k+1]] taken strictly left to right, ((v0 + v1) + v2) + ... — the order
+    in which Julia's `sparse(I,J,V)` combines duplicates and `b[k] += Δ` accumulates. (`np.add.reduceat` is NOT that:
+    it adds the first term to the sum of the others.)"""
+    ends = np.append(starts[1:], v.size)
+    out = v[starts].copy()
+    length = ends - starts
+    for p in range(1, int(length.max()) if length.size else 0):
+        m = length > p
+        out[m] = out[m] + v[starts[m] + p]
+    return out
 
 
 def _coo_to_csr(I, J, V, shape, seq=None) -> sp.csr_matrix:
@@ -291,7 +314,7 @@ def _coo_to_csr(I, J, V, shape, seq=None) -> sp.csr_matrix:
     new = np.ones(I.size, dtype=bool)
     new[1:] = (I[1:] != I[:-1]) | (J[1:] != J[:-1])
     starts = np.flatnonzero(new)
-    vals = np.add.reduceat(V, starts)
+    vals = _segment_sums(V, starts)
     rows, cols = I[starts], J[starts]
     indptr = np.zeros(shape[0] + 1, dtype=np.int64)
     np.add.at(indptr, rows + 1, 1)
@@ -310,7 +333,7 @@ def _accumulate(n, idx, vals, seq):
         new = np.ones(i.size, dtype=bool)
         new[1:] = i[1:] != i[:-1]
         starts = np.flatnonzero(new)
-        out[i[starts]] = np.add.reduceat(v, starts)
+        out[i[starts]] = _segment_sums(v, starts)
     return out
 
 
@@ -347,73 +370,103 @@ def do_isotropic_elliptic_assembly(cells, points, dinds: DirichletInds, point_ma
 # --------------------------------------------------------------------------------------
 # prepare_local_schurs / prepare_global_schur (EPDD.jl:389-546 / 212-369)
 # --------------------------------------------------------------------------------------
-def _prepare(cells, points, epart, sub: Subdomains, coeff, f, uexact, local: bool):
-    K, be, ue = _element_terms(cells, points, coeff, f, uexact)
+def _triplets(cells, sub: Subdomains, local: bool):
+    """Index side of the element loop (EPDD.jl:283-350 / 459-527): for every block the COO (row, col) pairs and, for
+    every pair, its sequence code s = 12*element + 3*i + j (stiffness term ΔK_ij, also the Dirichlet lifting when it
+    lands in a right-hand side) or 12*element + 9 + i (load term Δb_i). The code is both the reference's order of
+    accumulation and the address of the value, so the numeric side (host: `_values`, device: `AssemblyPlan`) needs
+    nothing else."""
     nel = cells.shape[1]
     owner = sub.node_owner[cells]                   # (3, nel)
     el = np.arange(nel)
-    n_Γ = sub.n_Γ
     gΓ = sub.ind_Γ_g2l[cells]
     gI = sub.ind_I_g2l[cells]
     # Γ_d-local index of every (vertex, element): only meaningful where owner == -1
     gΓd = np.full(cells.shape, -1, dtype=np.int64)
-    nnode = sub.node_owner.size
-    tmp = np.full(nnode, -1, dtype=np.int64)
+    tmp = np.full(sub.node_owner.size, -1, dtype=np.int64)
     for d in range(sub.ndom):
         tmp[sub.node_Γd[d]] = np.arange(sub.node_Γd[d].size)
         e = sub.elemd[d]
         gΓd[:, e] = tmp[cells[:, e]]
         tmp[sub.node_Γd[d]] = -1
-
-    A_II, A_IΓ, A_ΓΓ_parts = [], [], []
-    b_Id = []
-    bΓ_i, bΓ_v, bΓ_s = [], [], []
-    ΓΓ_glob = ([], [], [], [])
+    cat = np.concatenate
+    out = dict(II=[], IΓ=[], ΓΓ=[], bI=[], bΓ=None, ΓΓ_glob=None)
+    bΓ_i, bΓ_s = [], []
+    ΓΓ_glob = ([], [], [])
     for d in range(sub.ndom):
         e = sub.elemd[d]
-        ow, Ke, uee, bee = owner[:, e], K[:, :, e], ue[:, e], be[:, e]
+        ow = owner[:, e]
         gId, gΓe, gΓde, ele = gI[:, e], gΓ[:, e], gΓd[:, e], el[e]
-        II = ([], [], [], []); IΓ = ([], [], [], []); ΓΓ = ([], [], [], [])
-        bI = ([], [], [])
+        II = ([], [], []); IΓ = ([], [], []); ΓΓ = ([], [], [])
+        bI = ([], [])
         for i in range(3):
             for j in range(3):
                 s = ele * 12 + i * 3 + j
                 oi, oj = ow[i], ow[j]
                 m = (oi == -1) & (oj == -1)
                 if local:
-                    ΓΓ[0].append(gΓde[i][m]); ΓΓ[1].append(gΓde[j][m])
-                    ΓΓ[2].append(Ke[i, j][m]); ΓΓ[3].append(s[m])
+                    ΓΓ[0].append(gΓde[i][m]); ΓΓ[1].append(gΓde[j][m]); ΓΓ[2].append(s[m])
                 else:
-                    ΓΓ_glob[0].append(gΓe[i][m]); ΓΓ_glob[1].append(gΓe[j][m])
-                    ΓΓ_glob[2].append(Ke[i, j][m]); ΓΓ_glob[3].append(s[m])
+                    ΓΓ_glob[0].append(gΓe[i][m]); ΓΓ_glob[1].append(gΓe[j][m]); ΓΓ_glob[2].append(s[m])
                 m = (oi >= 0) & (oj >= 0)
-                II[0].append(gId[i][m]); II[1].append(gId[j][m]); II[2].append(Ke[i, j][m]); II[3].append(s[m])
+                II[0].append(gId[i][m]); II[1].append(gId[j][m]); II[2].append(s[m])
                 m = (oi >= 0) & (oj == -1)
-                IΓ[0].append(gId[i][m]); IΓ[1].append((gΓde if local else gΓe)[j][m])
-                IΓ[2].append(Ke[i, j][m]); IΓ[3].append(s[m])
-                # Dirichlet lifting (EPDD.jl:322-331 / 498-507)
+                IΓ[0].append(gId[i][m]); IΓ[1].append((gΓde if local else gΓe)[j][m]); IΓ[2].append(s[m])
+                # Dirichlet lifting (EPDD.jl:322-331 / 498-507): b[j] -= ΔK_ij * uexact(node i)
                 m = (oi == -2) & (oj == -1)
-                bΓ_i.append(gΓe[j][m]); bΓ_v.append(-(Ke[i, j][m] * uee[i][m])); bΓ_s.append(s[m])
+                bΓ_i.append(gΓe[j][m]); bΓ_s.append(s[m])
                 m = (oi == -2) & (oj >= 0)
-                bI[0].append(gId[j][m]); bI[1].append(-(Ke[i, j][m] * uee[i][m])); bI[2].append(s[m])
+                bI[0].append(gId[j][m]); bI[1].append(s[m])
         for i in range(3):
             s = ele * 12 + 9 + i
             m = ow[i] == -1
-            bΓ_i.append(gΓe[i][m]); bΓ_v.append(bee[i][m]); bΓ_s.append(s[m])
+            bΓ_i.append(gΓe[i][m]); bΓ_s.append(s[m])
             m = ow[i] >= 0
-            bI[0].append(gId[i][m]); bI[1].append(bee[i][m]); bI[2].append(s[m])
-        nI, nΓd = sub.node_Id[d].size, sub.node_Γd[d].size
-        cat = np.concatenate
-        A_II.append(_coo_to_csr(cat(II[0]), cat(II[1]), cat(II[2]), (nI, nI), cat(II[3])))
-        A_IΓ.append(_coo_to_csr(cat(IΓ[0]), cat(IΓ[1]), cat(IΓ[2]), (nI, nΓd if local else n_Γ), cat(IΓ[3])))
+            bI[0].append(gId[i][m]); bI[1].append(s[m])
+        out["II"].append(tuple(cat(v) for v in II))
+        out["IΓ"].append(tuple(cat(v) for v in IΓ))
         if local:
-            A_ΓΓ_parts.append(_coo_to_csr(cat(ΓΓ[0]), cat(ΓΓ[1]), cat(ΓΓ[2]), (nΓd, nΓd), cat(ΓΓ[3])))
-        b_Id.append(_accumulate(nI, cat(bI[0]), cat(bI[1]), cat(bI[2])))
-    b_Γ = _accumulate(n_Γ, np.concatenate(bΓ_i), np.concatenate(bΓ_v), np.concatenate(bΓ_s))
+            out["ΓΓ"].append(tuple(cat(v) for v in ΓΓ))
+        out["bI"].append(tuple(cat(v) for v in bI))
+    out["bΓ"] = (cat(bΓ_i), cat(bΓ_s))
+    if not local:
+        out["ΓΓ_glob"] = tuple(cat(v) for v in ΓΓ_glob)
+    return out
+
+
+def _values(seq, K, be, ue, rhs: bool):
+    """Value of every contribution from its sequence code: ΔK_ij; in a right-hand side -(ΔK_ij * uexact_i) or Δb_i."""
+    e, c = seq // 12, seq % 12
+    if not rhs:
+        return K.reshape(9, -1)[c, e]
+    lift = c < 9
+    cl = np.where(lift, c, 0)
+    v = -(K.reshape(9, -1)[cl, e] * ue[cl // 3, e])
+    return np.where(lift, v, be[np.where(lift, 0, c - 9), e])
+
+
+def _prepare(cells, points, epart, sub: Subdomains, coeff, f, uexact, local: bool):
+    K, be, ue = _element_terms(cells, points, coeff, f, uexact)
+    T = _triplets(cells, sub, local)
+    n_Γ = sub.n_Γ
+    A_II, A_IΓ, A_ΓΓ_parts, b_Id = [], [], [], []
+    for d in range(sub.ndom):
+        nI, nΓd = sub.node_Id[d].size, sub.node_Γd[d].size
+        I, J, S = T["II"][d]
+        A_II.append(_coo_to_csr(I, J, _values(S, K, be, ue, False), (nI, nI), S))
+        I, J, S = T["IΓ"][d]
+        A_IΓ.append(_coo_to_csr(I, J, _values(S, K, be, ue, False), (nI, nΓd if local else n_Γ), S))
+        if local:
+            I, J, S = T["ΓΓ"][d]
+            A_ΓΓ_parts.append(_coo_to_csr(I, J, _values(S, K, be, ue, False), (nΓd, nΓd), S))
+        I, S = T["bI"][d]
+        b_Id.append(_accumulate(nI, I, _values(S, K, be, ue, True), S))
+    I, S = T["bΓ"]
+    b_Γ = _accumulate(n_Γ, I, _values(S, K, be, ue, True), S)
     if local:
         return A_II, A_IΓ, A_ΓΓ_parts, b_Id, b_Γ
-    cat = np.concatenate
-    A_ΓΓ = _coo_to_csr(cat(ΓΓ_glob[0]), cat(ΓΓ_glob[1]), cat(ΓΓ_glob[2]), (n_Γ, n_Γ), cat(ΓΓ_glob[3]))
+    I, J, S = T["ΓΓ_glob"]
+    A_ΓΓ = _coo_to_csr(I, J, _values(S, K, be, ue, False), (n_Γ, n_Γ), S)
     return A_II, A_IΓ, A_ΓΓ, b_Id, b_Γ
 
 
@@ -425,6 +478,103 @@ def prepare_local_schurs(cells, points, epart, sub: Subdomains, coeff: Coeff, f,
 def prepare_global_schur(cells, points, epart, sub: Subdomains, coeff: Coeff, f, uexact):
     """`prepare_global_schur` (EPDD.jl:212-369): (A_IId, A_IΓd, A_ΓΓ, b_Id, b_Γ), Γ-global columns."""
     return _prepare(cells, points, epart, sub, coeff, f, uexact, local=False)
+
+
+@dataclass
+class AssemblyPlan:
+    """The index half of `prepare_local_schurs` (EPDD.jl:389-546) for a FIXED mesh, partition, `f` and `uexact`: what
+    Example07's realization loop (:162-171) recomputes for every coefficient draw although only `a` changes.
+
+    Output entries, in this order: the stored values of A_IIdd[0..ndom), A_IΓdd[0..ndom), A_ΓΓdd[0..ndom) — the `nzval`
+    of Julia's CSC matrices, which is also what `mi_schur_matfree_*create` / `_set_values` take — then b_Id[0..ndom), b_Γ. Entry k is the sum, in the reference's
+    element order, of the contributions `ccode[cptr[k]:cptr[k+1]]`; a contribution code is 12*element + 3*i + j
+    (ΔK_ij = Δa*G_ij/4/Area; in a right-hand side: -(ΔK_ij*ue_i)) or 12*element + 9 + i (Δb_i, coefficient-free).
+    `api.AssemblyPlan(ctx, plan)` runs it on the GPU; `blocks(values)` rebuilds the scipy matrices on the host."""
+    cells: np.ndarray
+    G: np.ndarray          # (9, nel)
+    area: np.ndarray       # (nel,)
+    ue: np.ndarray         # (3, nel)
+    be: np.ndarray         # (3, nel)
+    cptr: np.ndarray
+    ccode: np.ndarray
+    n_matrix_entries: int
+    layout: dict           # name -> list of (offset, count) per subdomain (b_Γ: single tuple)
+    patterns: dict         # name -> list of (indptr, indices, shape)
+    n_node: int
+
+    @property
+    def n_entries(self) -> int:
+        return self.cptr.size - 1
+
+    def blocks(self, values: np.ndarray):
+        """(A_IIdd, A_IΓdd, A_ΓΓdd, b_Id, b_Γ) from a flat value array, as `prepare_local_schurs` returns them."""
+        values = np.asarray(values, dtype=np.float64)
+        out = []
+        for name in ("II", "IΓ", "ΓΓ"):
+            mats = []
+            for (off, cnt), (indptr, indices, shape) in zip(self.layout[name], self.patterns[name]):
+                if name == "IΓ":
+                    m = sp.csc_matrix((values[off:off + cnt].copy(), indices, indptr), shape=shape).tocsr()
+                else:
+                    m = sp.csr_matrix((values[off:off + cnt].copy(), indices, indptr), shape=shape)
+                m.has_sorted_indices = True
+                mats.append(m)
+            out.append(mats)
+        out.append([values[off:off + cnt].copy() for off, cnt in self.layout["bI"]])
+        off, cnt = self.layout["bΓ"]
+        out.append(values[off:off + cnt].copy())
+        return tuple(out)
+
+
+def make_assembly_plan(cells, points, epart, sub: Subdomains, f, uexact) -> AssemblyPlan:
+    x, y = points[0][cells], points[1][cells]
+    G, Area = _element_geometry(x, y)
+    fv = _eval(f, x, y)
+    be = np.empty((3, cells.shape[1]))
+    for i in range(3):
+        j, k = (i + 1) % 3, (i + 2) % 3
+        be[i] = (2 * fv[i] + fv[j] + fv[k]) * Area / 12
+    ue = _eval(uexact, x, y)
+    T = _triplets(cells, sub, local=True)
+    counts, codes = [], []
+    layout = dict(II=[], IΓ=[], ΓΓ=[], bI=[], bΓ=None)
+    patterns = dict(II=[], IΓ=[], ΓΓ=[])
+    off = 0
+    for name in ("II", "IΓ", "ΓΓ"):
+        for d in range(sub.ndom):
+            I, J, S = T[name][d]
+            nI, nΓd = sub.node_Id[d].size, sub.node_Γd[d].size
+            shape = dict(II=(nI, nI), IΓ=(nI, nΓd), ΓΓ=(nΓd, nΓd))[name]
+            if name == "IΓ":
+                I, J = J, I            # A_IΓdd is stored by COLUMN (the CSC arrays the C ABI takes = CSR of A_ΓIdd)
+            order = np.lexsort((S, J, I))
+            I, J, S = I[order], J[order], S[order]
+            new = np.ones(I.size, dtype=bool)
+            new[1:] = (I[1:] != I[:-1]) | (J[1:] != J[:-1])
+            starts = np.flatnonzero(new)
+            indptr = np.zeros((shape[1] if name == "IΓ" else shape[0]) + 1, dtype=np.int64)
+            np.add.at(indptr, I[starts] + 1, 1)
+            patterns[name].append((np.cumsum(indptr), J[starts].astype(np.int64), shape))
+            counts.append(np.diff(np.append(starts, I.size)))
+            codes.append(S)
+            layout[name].append((off, starts.size))
+            off += starts.size
+    n_matrix = off
+    rhs = [(T["bI"][d], sub.node_Id[d].size) for d in range(sub.ndom)] + [(T["bΓ"], sub.n_Γ)]
+    for k, ((idx, S), n) in enumerate(rhs):
+        order = np.lexsort((S, idx))
+        counts.append(np.bincount(idx, minlength=n).astype(np.int64))
+        codes.append(S[order])
+        if k < sub.ndom:
+            layout["bI"].append((off, n))
+        else:
+            layout["bΓ"] = (off, n)
+        off += n
+    cptr = np.zeros(off + 1, dtype=np.int64)
+    np.cumsum(np.concatenate(counts), out=cptr[1:])
+    return AssemblyPlan(np.ascontiguousarray(cells, dtype=np.int64), np.ascontiguousarray(G.reshape(9, -1)),
+                        np.ascontiguousarray(Area), np.ascontiguousarray(ue), np.ascontiguousarray(be), cptr,
+                        np.concatenate(codes).astype(np.int64), n_matrix, layout, patterns, int(points.shape[1]))
 
 
 # --------------------------------------------------------------------------------------

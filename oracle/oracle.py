@@ -465,3 +465,28 @@ def initcg(A, b, x, W, maxit=0, eps=1e-7):
 
 def initpcg(A, b, x, M, W, maxit=0, eps=1e-7):
     return pcg(A, b, _init_guess(A, b, x, W), M, maxit, eps)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# checker for the device assembly kernel — executes an `fem.AssemblyPlan` in numpy with the
+# reference's arithmetic (EPDD.jl:260-269 Δa, :294 ΔK_ij, :322-349 right-hand sides), entry by entry, in order.
+def run_assembly_plan(plan, a_nodal):
+    a = np.asarray(a_nodal, dtype=np.float64)[plan.cells]
+    Δa = np.zeros(plan.cells.shape[1])
+    for j in range(3):
+        Δa = Δa + a[j]
+    Δa = Δa / 3.0
+    e, c = plan.ccode // 12, plan.ccode % 12
+    stiff = c < 9
+    cs = np.where(stiff, c, 0)
+    K = Δa[e] * plan.G[cs, e] / 4 / plan.area[e]
+    entry = np.repeat(np.arange(plan.n_entries), np.diff(plan.cptr))
+    term = np.where(entry < plan.n_matrix_entries, K,
+                    np.where(stiff, -(K * plan.ue[cs // 3, e]), plan.be[np.where(stiff, 0, c - 9), e]))
+    out = np.zeros(plan.n_entries)
+    cnt = np.diff(plan.cptr)
+    for p in range(int(cnt.max()) if cnt.size else 0):      # strictly left to right, as `sparse(I,J,V)` / `b[k] +=` do
+        m = np.flatnonzero(cnt > p)
+        t = term[plan.cptr[m] + p]
+        out[m] = t if p == 0 else out[m] + t
+    return out

@@ -355,3 +355,29 @@ def test_host_dense_kernels_of_the_eig_restart(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "dense_small_check.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
+
+
+# ------------------------------------------------------------------ assembly plan: index half on the host
+@pytest.mark.parametrize("px,py", [(2, 2), (3, 2)])
+def test_assembly_plan_reproduces_prepare_local_schurs(fem, orc, px, py):
+    """The plan's (entry -> ordered contributions) structure, executed in numpy, gives bit for bit the blocks and
+    right-hand sides of `prepare_local_schurs` for any coefficient — this pins the symbolic half without a GPU."""
+    N = 36
+    mesh = fem.get_mesh(N)
+    dinds = fem.get_dirichlet_inds(mesh.points, mesh.point_marker)
+    epart, npart = fem.mesh_partition(mesh, px, py)
+    sub = fem.set_subdomains(mesh.cells, mesh.cell_neighbors, epart, npart, dinds.dirichlet_g2l)
+    f = lambda x, y: np.sin(3 * x) + y          # noqa: E731
+    ue = lambda x, y: 0.5 + x * y               # noqa: E731
+    plan = fem.make_assembly_plan(mesh.cells, mesh.points, epart, sub, f, ue)
+    for seed in (1, 2):
+        a = np.exp(np.random.default_rng(seed).standard_normal(mesh.points.shape[1]))
+        want = fem.prepare_local_schurs(mesh.cells, mesh.points, epart, sub, a, f, ue)
+        got = plan.blocks(orc.run_assembly_plan(plan, a))
+        for k in range(3):
+            for A, B in zip(got[k], want[k]):
+                assert A.shape == B.shape and np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+                assert np.array_equal(A.data, B.data)
+        for u, v in zip(got[3], want[3]):
+            assert np.array_equal(u, v)
+        assert np.array_equal(got[4], want[4])

@@ -58,6 +58,20 @@ it, dt = rate(lambda: api.eigdefpcg(S, bd, torch.zeros_like(bd), M, We, spdim)[1
 print(f"eigdefpcg nvec={nvec}       : it={it} {dt * 1e6:8.1f} us/solve {(it - 1) / dt:9.0f} it/s")
 it, dt = rate(lambda: api.eigcg(S, bd, torch.zeros_like(bd), nvec, spdim)[1], 10)
 print(f"eigcg (no precond)  : it={it} {dt * 1e6:8.1f} us/solve {(it - 1) / dt:9.0f} it/s")
+# f3: numeric assembly of all blocks and right-hand sides on the device vs the host element loop
+plan = fem.make_assembly_plan(P.mesh.cells, P.mesh.points, P.epart, P.sub, lambda x, y: -1.0 + 0 * x, lambda x, y: 0.734 + 0 * x)
+dev = api.AssemblyPlan(ctx, plan)
+ad = torch.from_numpy(np.exp(g)).cuda()
+dev.run(ad); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    v = dev.run(ad)
+ctx.synchronize(); t1 = time.perf_counter()
+nb = 4 * plan.ccode.size + 8 * plan.n_entries * 2 + 8 * plan.ccode.size
+print(f"device assembly     : {plan.n_entries} entries, {plan.ccode.size} contributions: {(t1 - t0) / 20 * 1e3:7.3f} ms/realization "
+      f"(~{nb / ((t1 - t0) / 20) / 1e9:6.0f} GB/s of code+G+out streams)")
+t0 = time.perf_counter(); fem.prepare_local_schurs(P.mesh.cells, P.mesh.points, P.epart, P.sub, np.exp(g), lambda x, y: -1.0 + 0 * x, lambda x, y: 0.734 + 0 * x); t1 = time.perf_counter()
+print(f"host element loop   : {(t1 - t0) * 1e3:7.1f} ms/realization (numpy)")
 if os.environ.get("MEASURE_SKIP_MATFREE"):
     sys.exit(0)
 Sm = api.MatrixFreeLocalSchurs(ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, P.sub.node_Γ_cnt, P.solvers)

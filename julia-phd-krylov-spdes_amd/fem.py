@@ -858,7 +858,7 @@ class SchurProblem:
 
 def build_schur_problem(N: int, px: int, py: int, coeff: Coeff, f, uexact,
                         assemble: bool = True, precond: bool = True, dom_slice=None,
-                        mesh: Optional[Mesh] = None, partition=None) -> SchurProblem:
+                        mesh: Optional[Mesh] = None, partition=None, blocks=None, sub: Optional[Subdomains] = None) -> SchurProblem:
     """Example03:45-150 set-up flow on the synthetic mesh (mesh → partition → maps →
     local blocks → b_schur → assembled S_d → Neumann-Neumann pseudo-inverses).
 
@@ -868,12 +868,17 @@ def build_schur_problem(N: int, px: int, py: int, coeff: Coeff, f, uexact,
     (+ b_Γ on the rank that owns subdomain 0), so that the sum over ranks is the full b_schur.
     `mesh` / `partition=(epart, npart)` replace the structured substitutes, e.g. with files written by the
     reference's Triangle + METIS pipeline (io.load_mesh / io.load_partition).
+    `blocks=(A_IIdd, A_IΓdd, A_ΓΓdd, b_Id, b_Γ)` skips the element loop (e.g. `AssemblyPlan.blocks` of values
+    assembled on the GPU; `coeff` is then unused) and `sub` re-uses the subdomain maps of an earlier call.
     """
     mesh = get_mesh(N) if mesh is None else mesh
     dinds = get_dirichlet_inds(mesh.points, mesh.point_marker)
     epart, npart = mesh_partition(mesh, px, py) if partition is None else partition
-    sub = set_subdomains(mesh.cells, mesh.cell_neighbors, epart, npart, dinds.dirichlet_g2l)
-    A_II, A_IΓ, A_ΓΓ, b_Id, b_Γ = prepare_local_schurs(mesh.cells, mesh.points, epart, sub, coeff, f, uexact)
+    if sub is None:
+        sub = set_subdomains(mesh.cells, mesh.cell_neighbors, epart, npart, dinds.dirichlet_g2l)
+    if blocks is None:
+        blocks = prepare_local_schurs(mesh.cells, mesh.points, epart, sub, coeff, f, uexact)
+    A_II, A_IΓ, A_ΓΓ, b_Id, b_Γ = blocks
     lo, hi = (0, sub.ndom) if dom_slice is None else dom_slice
     loc = range(lo, hi)
     b_schur = np.array(b_Γ, copy=True) if lo == 0 else np.zeros_like(b_Γ)

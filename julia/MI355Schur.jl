@@ -16,6 +16,7 @@ import LinearAlgebra: mul!, ldiv!
 export MiContext, MiOperator, MiPrecond,
        LocalSchurs, MatrixFreeLocalSchurs, GlobalSchur, NeumannNeumannSchurPreconditioner,
        apply_local_schurs, apply_global_schur, apply_neumann_neumann_schur,
+       AssemblyPlan, assemble!, set_values!, get_schur_rhs,
        cg, pcg, defcg, defpcg, eigcg, eigpcg, eigdefcg, eigdefpcg, initcg, initpcg
 
 const lib = get(ENV, "MI355SCHUR_LIB", "libmi355schur")
@@ -230,6 +231,36 @@ cg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}; maxit=0) = solve(:cg, 
 pcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, M::MiOperator; maxit=0) = solve(:pcg, A, M, b, x, nothing, maxit)
 defcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, W::Matrix{Float64}; maxit=0) = solve(:defcg, A, nothing, b, x, W, maxit)
 defpcg(A::MiOperator, b::Vector{Float64}, x::Vector{Float64}, W::Matrix{Float64}, M::MiOperator; maxit=0) = solve(:defpcg, A, M, b, x, W, maxit)
+
+# On-device numeric assembly (the element loop of prepare_local_schurs, EPDD.jl:389-546, for a new coefficient vector).
+# `cptr`/`ccode` (0-based, Int64) are recorded ONCE by running that loop symbolically: wherever the reference pushes
+# (I, J, ΔKij) or does `b[k] += Δ` for element iel and local pair (i, j), record the code 12*(iel-1) + 3*(i-1) + (j-1)
+# (or 12*(iel-1) + 9 + (i-1) for a load term) under the stored entry it lands in, in loop order.
+mutable struct AssemblyPlan
+  h::Ptr{Cvoid}; n_node::Int; n_entries::Int; ctx
+end
+function AssemblyPlan(ctx::MiContext, cells::Matrix{Int}, n_node::Int, G::Matrix{Float64}, area::Vector{Float64},
+                      ue::Matrix{Float64}, be::Matrix{Float64}, n_matrix_entries::Int, cptr::Vector{Int64}, ccode::Vector{Int64})
+  nel = size(cells, 2)
+  ct = permutedims(cells)                  # library layout: vertex i of every element contiguous (3 x nel row-major)
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  check(ccall((:mi_assembly_plan_create, lib), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ref{Ptr{Cvoid}}),
+        ctx.h, nel, n_node, ct, 1, permutedims(G), area, permutedims(ue), permutedims(be), length(cptr) - 1, n_matrix_entries, cptr, ccode, h))
+  p = AssemblyPlan(h[], n_node, length(cptr) - 1, ctx)
+  finalizer(q -> ccall((:mi_assembly_plan_destroy, lib), Cint, (Ptr{Cvoid},), q.h), p)
+  return p
+end
+function assemble!(values::Vector{Float64}, p::AssemblyPlan, a::Vector{Float64})
+  check(ccall((:mi_assembly_run, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), p.h, a, values)); values
+end
+set_values!(S::MiOperator, ii, ig, gg) =
+  check(ccall((:mi_schur_matfree_set_values, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+              S.h, ii === nothing ? C_NULL : ii, ig === nothing ? C_NULL : ig, gg === nothing ? C_NULL : gg))
+function get_schur_rhs(S::MiOperator, b_I::Vector{Float64}, b_Γ::Vector{Float64})      # EPDD.jl:835-864
+  out = similar(b_Γ)
+  check(ccall((:mi_schur_matfree_rhs, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), S.h, b_I, b_Γ, out)); out
+end
 
 # eigCG family and Init-CG (eigcg.jl:27-33, 143-150; defcg.jl:111-116, 337-343; initcg.jl:28-33, 106-111).
 # Same positional orders and 4-tuple / 3-tuple returns as the reference (Example09_..._Functions.jl:314, 364).

@@ -63,6 +63,26 @@ __device__ __forceinline__ double block_sum_t(double v, double *sm) {
   __syncthreads();
   return t;
 }
+// Two workgroup sums with ONE barrier: per-wave shuffle trees, then every wave reduces the NTH/64 wave results with a
+// second shuffle tree (no serial LDS chain, no second barrier). Fixed tree: deterministic, identical in every workgroup.
+// `sm` has 2*(NTH/64) doubles and must not be reused before the next barrier.
+template <int NTH>
+__device__ __forceinline__ void block_sum2_t(double &a, double &b, double *sm) {
+  constexpr int NW = NTH / 64;
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sm[w] = a; sm[NW + w] = b; }
+  __syncthreads();
+  double ta = lane < NW ? sm[lane] : 0.0, tb = lane < NW ? sm[NW + lane] : 0.0;
+#pragma unroll
+  for (int off = NW / 2; off > 0; off >>= 1) {
+    ta += __shfl_down(ta, off, 64);
+    tb += __shfl_down(tb, off, 64);
+  }
+  a = __shfl(ta, 0, 64);
+  b = __shfl(tb, 0, 64);
+}
 // Sum of `g` per-workgroup partials, in a fixed order, identical in every workgroup.
 __device__ __forceinline__ double sum_partials(const double *part, int g, double *sm) {
   double v = 0.0;
@@ -319,6 +339,9 @@ struct DenseMeta {
   const int *out_pos;     // [nloc] slot g*W + j of every local row
 };
 constexpr int GEMV_PANEL = 2048;  // doubles of x_d staged per pass (16 KiB LDS)
+#ifndef MI355_OPERAND_FIRST
+#define MI355_OPERAND_FIRST 1   // 0: matrix stream first (measured 7 % slower in the folded PCG launches)
+#endif
 #ifndef MI355_GEMV_GU
 #define MI355_GEMV_GU 4        // 16-byte loads per lane and row in one group (2 and 8 measured slower, profiles/)
 #endif
@@ -396,10 +419,39 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_batched(DenseMeta m, const 
   const GemvTile t = m.tiles[blockIdx.x];
   const int off = t.loc_off, n = t.n;
   GemvRows<RPW> rows;
+#if !MI355_OPERAND_FIRST
   rows.begin(m, t);
+#endif
   for (int c0 = 0; c0 < t.ld; c0 += GEMV_PANEL) {
     const int pw = min(GEMV_PANEL, t.ld - c0);  // multiple of 16
     if (c0) __syncthreads();
+#if MI355_OPERAND_FIRST
+    // Vector-memory results return in issue order: the operand gather (index -> value, two dependent loads) is issued
+    // BEFORE the first group of the matrix stream, so staging waits for its own loads only, not for 128 KB of matrix.
+    constexpr int XPT = (GEMV_PANEL + NTH - 1) / NTH;
+    int gi[XPT];
+#pragma unroll
+    for (int q = 0; q < XPT; ++q) {
+      const int j = c0 + q * NTH + (int)threadIdx.x;
+      gi[q] = (q * NTH + (int)threadIdx.x < pw && j < n) ? m.gidx[off + j] : -1;
+    }
+    double xv[XPT];
+#pragma unroll
+    for (int q = 0; q < XPT; ++q) {
+      const int j = c0 + q * NTH + (int)threadIdx.x;
+      xv[q] = 0.0;
+      if (gi[q] >= 0) {
+        xv[q] = x[gi[q]];
+        if (SCALE) xv[q] = xv[q] / m.cnt[off + j];
+      }
+    }
+    if (c0 == 0) rows.begin(m, t);
+#pragma unroll
+    for (int q = 0; q < XPT; ++q) {
+      const int l = q * NTH + (int)threadIdx.x;
+      if (l < pw) xs[l] = xv[q];
+    }
+#else
     for (int l = threadIdx.x; l < pw; l += NTH) {
       const int j = c0 + l;
       double v = 0.0;
@@ -409,6 +461,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_batched(DenseMeta m, const 
       }
       xs[l] = v;
     }
+#endif
     __syncthreads();
     rows.panel(xs, c0, pw);
   }
@@ -486,13 +539,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   SolverState *st = f.st;
   if (st->done) return;
   __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
-  __shared__ double sm[NTH / 64 + 1];
+  __shared__ double sm[2 * (NTH / 64)];
   __shared__ double rowv[NR], rowc0[NR], rowc1[NR];
   const GemvTile t = m.tiles[blockIdx.x];
   const int off = t.loc_off, W = f.W, n = t.n;
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  if (threadIdx.x < NR) { rowc0[threadIdx.x] = 0.0; rowv[threadIdx.x] = 0.0; }  // visible after the barrier of the sums
   GemvRows<RPW> rows;
+#if !MI355_OPERAND_FIRST
   rows.begin(m, t);  // matrix stream in flight from here on
+#endif
 
   // ---- every load of the prologue is issued before the first barrier (one memory round trip), all contiguous
   const long long it0 = st->it, it_nxt0 = st->it_nxt, maxit = st->maxit, cap = st->res_cap;
@@ -553,11 +609,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     }
   }
 
+#if MI355_OPERAND_FIRST
+  rows.begin(m, t);  // matrix stream in flight from here on: issued AFTER the prologue's loads (results return in issue order)
+#endif
   // ---- scalars
   double coef;  // alpha (PHASE 1) or beta (PHASE 0)
   if (PHASE == 1) {
     const bool first = first1;
-    const double d = block_sum_t<NTH>(pa, sm);
+    block_sum2_t<NTH>(pa, pb, sm);
+    const double d = pa;
     coef = first ? 0.0 : rTz0 / d;
     if (lead) {
       st->d = d; st->alpha = coef;
@@ -566,8 +626,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     }
   } else {
     const long long it_new = it0 + 1;
-    const double rr = block_sum_t<NTH>(pa, sm);
-    const double rz = block_sum_t<NTH>(pb, sm);
+    block_sum2_t<NTH>(pa, pb, sm);
+    const double rr = pa, rz = pb;
     const double res = sqrt(rr);
     const bool stop = !((it_new < maxit) && (res > tol));
     coef = 1. / old;
@@ -582,8 +642,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   }
 
   // ---- operand of this GEMV into LDS; rows of this tile: value for the epilogue dot, owners' stores
-  if (threadIdx.x < NR) { rowc0[threadIdx.x] = 0.0; rowv[threadIdx.x] = 0.0; }
-  __syncthreads();
 #pragma unroll
   for (int q = 0; q < FOLD_CPT; ++q) {
     const int j = q * NTH + threadIdx.x;
@@ -640,11 +698,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {  // per-tile partials of the next dot products: one shuffle tree over the NR row terms
     double a = 0.0, b = 0.0;
-    for (int i = 0; i < NR; ++i) { a += rowc1[i]; b += rowc0[i]; }
-    if (PHASE == 1) { f.part_out1[blockIdx.x] = a; f.part_out0[blockIdx.x] = b; }
-    else f.part_out0[blockIdx.x] = a;
+    for (int i = threadIdx.x; i < NR; i += 64) { a += rowc1[i]; b += rowc0[i]; }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (threadIdx.x == 0) {
+      if (PHASE == 1) { f.part_out1[blockIdx.x] = a; f.part_out0[blockIdx.x] = b; }
+      else f.part_out0[blockIdx.x] = a;
+    }
   }
 }
 

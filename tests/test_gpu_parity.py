@@ -266,7 +266,9 @@ def test_error_conventions(pkg, ctx, toy):
     P = toy
     S, M = gpu_ops(pkg, ctx, P)
     n, b = P.sub.n_Γ, P.b_schur
-    W = np.asfortranarray(np.column_stack([b, b]))                        # rank-deficient W
+    # rank-deficient W with an exactly zero pivot (two equal columns give U[2,2] == 0 only if fl(1/a)*a == 1 for
+    # a = b'Sb, in LAPACK as here: value-dependent; a zero column is singular for every value)
+    W = np.asfortranarray(np.column_stack([b, np.zeros(n)]))
     with pytest.raises(api.SingularException):
         api.defpcg(S, b, np.zeros(n), W, M)
     x, it, res = api.pcg(S, b, np.zeros(n), M)                            # the context is still usable

@@ -189,7 +189,7 @@ def test_deflation_semantics(orc, toy):
     xq, itq, _ = orc.defpcg(S, b, x0, W, M)
     assert itq <= itp and np.linalg.norm(xq - xp) < 1e-5 * np.linalg.norm(xp)
     # rank-deficient W => SingularException from `WtAW \ mu` (README "To do")
-    Wbad = np.asfortranarray(np.column_stack([W[:, 0], W[:, 0]]))
+    Wbad = np.asfortranarray(np.column_stack([W[:, 0], np.zeros(n)]))   # an exactly zero pivot for any value of w'Sw
     with pytest.raises(orc.SingularException):
         orc.defpcg(S, b, x0, Wbad, M)
 

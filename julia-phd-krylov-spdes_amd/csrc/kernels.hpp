@@ -24,6 +24,13 @@ struct SolverState {
   int overflow;               // res_norm capacity hit (BoundsError in the reference)
 };
 
+// What the host reads back after a replay (pinned memory, written by k_solve_end or copied by fetch_flags)
+struct PinnedFlags {
+  long long it;
+  int done;
+  int overflow;
+};
+
 // ------------------------------------------------------------------ reductions
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -855,6 +862,27 @@ __global__ __launch_bounds__(NT) void k_update_p(int n, SolverState *st, const d
     st->done = !((it < st->maxit) && (res > st->tol));
   }
 }
+// Entry and exit of a solve, one launch each instead of a handful of small copies (each a separate blit on the stream):
+// in:  b, x0 -> workspace; eps / maxit / res_cap -> state block.
+__global__ __launch_bounds__(NT) void k_solve_begin(int n, const double *__restrict__ b_in, const double *__restrict__ x_in,
+                                                    double *__restrict__ b, double *__restrict__ x, SolverState *st, double eps,
+                                                    long long maxit, long long res_cap) {
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) { b[i] = b_in[i]; x[i] = x_in[i]; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st->eps = eps; st->maxit = maxit; st->res_cap = res_cap; }
+}
+// out: x -> caller's vector (device), `it` / done / overflow and the first min(it, ncap) residual norms -> pinned host memory.
+__global__ __launch_bounds__(NT) void k_solve_end(int n, const SolverState *st, int fold, const double *__restrict__ x,
+                                                  double *__restrict__ x_out, const double *__restrict__ res_norm,
+                                                  double *__restrict__ res_stage, long long ncap, PinnedFlags *flags) {
+  const long long it = fold ? st->it_nxt : st->it;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) x_out[i] = x[i];
+  if (res_stage) {
+    const long long m = it < ncap ? it : ncap;
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < m; i += (long long)gridDim.x * NT) res_stage[i] = res_norm[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { flags->it = it; flags->done = st->done; flags->overflow = st->overflow; }
+}
+
 // ------------------------------------------------------------------ fused single-workgroup kernels (n <= 8192)
 // On the Schur system the Γ-vectors are tiny (n_Γ ≈ 4 k): one 1024-thread workgroup keeps its
 // share of every vector in registers and does Γ-sum + dot + update in one launch, so a PCG

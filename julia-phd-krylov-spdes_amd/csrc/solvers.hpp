@@ -21,15 +21,6 @@
 
 namespace mi {
 
-struct PinnedFlags {
-  long long it;
-  int done;
-  int overflow;
-};
-struct PinnedParams {
-  double eps;
-  long long maxit, res_cap;
-};
 
 constexpr int64_t RES_STAGE = 8192;
 
@@ -63,7 +54,6 @@ struct SolverWorkspace {
   int e_spdim = 0, e_nvec = 0;
   bool e_av = false;
   PinnedFlags *flags = nullptr;    // 2 slots, pinned
-  PinnedParams *params = nullptr;  // pinned source of eps / maxit / res_cap
   double *res_stage = nullptr;     // pinned landing zone for short residual histories
   hipEvent_t ev[2] = {nullptr, nullptr};
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -82,14 +72,12 @@ struct SolverWorkspace {
     r = (double *)q; q += vec; z = (double *)q; q += vec; p = (double *)q; q += vec;
     Ap = (double *)q; q += vec; x = (double *)q; q += vec; b = (double *)q; q += vec;
     MI_HIP(hipHostMalloc((void **)&flags, 2 * sizeof(PinnedFlags)));
-    MI_HIP(hipHostMalloc((void **)&params, sizeof(PinnedParams)));
     MI_HIP(hipHostMalloc((void **)&res_stage, RES_STAGE * sizeof(double)));
     for (auto &e : ev) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   ~SolverWorkspace() {
     drop_graphs();
     if (flags) (void)hipHostFree(flags);
-    if (params) (void)hipHostFree(params);
     if (res_stage) (void)hipHostFree(res_stage);
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
   }
@@ -391,11 +379,9 @@ struct Krylov {
     if ((size_t)cap_dev > ws.res_norm.n) { ws.drop_graphs(); ws.res_norm.alloc((size_t)cap_dev); }
     if (nvec > 0) ws.ensure_deflation(nvec);
     const size_t vb = sizeof(double) * (size_t)n;
-    MI_HIP(hipMemcpyAsync(ws.b, b_in, vb, hipMemcpyDeviceToDevice, s));
-    MI_HIP(hipMemcpyAsync(ws.x, x_in, vb, hipMemcpyDeviceToDevice, s));
-    *ws.params = PinnedParams{eps, (long long)maxit, (long long)cap_dev};
-    MI_HIP(hipMemcpyAsync(&ws.st->eps, &ws.params->eps, sizeof(double), hipMemcpyHostToDevice, s));
-    MI_HIP(hipMemcpyAsync(&ws.st->maxit, &ws.params->maxit, 2 * sizeof(long long), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_solve_begin, dim3(g), dim3(NT), 0, s, n, b_in, x_in, ws.b, ws.x, ws.st, eps, (long long)maxit,
+                       (long long)cap_dev);
+    MI_HIP(hipGetLastError());
     if (nvec > 0) {
       MI_HIP(hipMemcpyAsync(ws.W.p, W_in, vb * nvec, hipMemcpyDeviceToDevice, s));
       for (int v = 0; v < nvec; ++v) A->apply(ws.W.p + (size_t)v * n, ws.AW.p + (size_t)v * n, nullptr);  // WtA[v,:] = A*W[:,v]
@@ -428,16 +414,15 @@ struct Krylov {
             int64_t res_cap, int64_t *it_out) {
     int64_t cap_dev = 0;
     begin(b_in, x_io, W_in, maxit, eps, cap_dev);
-    const size_t vb = sizeof(double) * (size_t)n;
 
     // ---- set-up tail + loop
     bool use_graph = ctx->chunk > 0 && A->graph_safe() && (!M || M->graph_safe()) && !ctx->no_graph;
     const int64_t ncap = std::min<int64_t>(res_cap, cap_dev);
     const bool spec_res = res_host && ncap > 0 && ncap <= RES_STAGE;
     auto enqueue_results = [&](int slot) {
-      fetch_flags(slot);
-      MI_HIP(hipMemcpyAsync(x_io, ws.x, vb, hipMemcpyDeviceToDevice, s));
-      if (spec_res) MI_HIP(hipMemcpyAsync(ws.res_stage, ws.res_norm.p, sizeof(double) * ncap, hipMemcpyDeviceToHost, s));
+      hipLaunchKernelGGL(k_solve_end, dim3(g), dim3(NT), 0, s, n, ws.st, (int)fold, ws.x, x_io, ws.res_norm.p,
+                         spec_res ? ws.res_stage : (double *)nullptr, (long long)ncap, &ws.flags[slot]);
+      MI_HIP(hipGetLastError());
     };
     if (use_graph) {
       const GraphKey pk{A, M, nvec, 0};

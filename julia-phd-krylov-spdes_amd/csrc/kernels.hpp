@@ -22,6 +22,7 @@ struct SolverState {
   long long it_nxt;           // folded PCG: iteration counter written one launch ahead of `it`
   int done;
   int overflow;               // res_norm capacity hit (BoundsError in the reference)
+  int x0_zero;                // the initial guess of this solve is identically zero: `A*x0` need not stream A (set-up only)
 };
 
 // What the host reads back after a replay (pinned memory, written by k_solve_end or copied by fetch_flags)
@@ -419,12 +420,20 @@ struct GemvRows {
 
 template <int RPW, bool SCALE, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_gemv_batched(DenseMeta m, const double *__restrict__ x,
-                                                             double *__restrict__ yslots, const int *done) {
+                                                             double *__restrict__ yslots, const int *done,
+                                                             const int *zero_x) {
   constexpr int NTH = 64 * WAVES;
   if (done && *done) return;
   __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
   const GemvTile t = m.tiles[blockIdx.x];
   const int off = t.loc_off, n = t.n;
+  if (zero_x && *zero_x) {  // x is identically zero (set-up of a solve from x0 = 0): the products are +0, nothing to stream
+    const int row_base = t.row0 + (threadIdx.x >> 6) * RPW;
+    if ((threadIdx.x & 63) == 0)
+      for (int k = 0; k < RPW; ++k)
+        if (row_base + k < n) yslots[m.out_pos[off + row_base + k]] = 0.0;
+    return;
+  }
   GemvRows<RPW> rows;
 #if !MI355_OPERAND_FIRST
   rows.begin(m, t);
@@ -867,14 +876,23 @@ __global__ __launch_bounds__(NT) void k_update_p(int n, SolverState *st, const d
 __global__ __launch_bounds__(NT) void k_solve_begin(int n, const double *__restrict__ b_in, const double *__restrict__ x_in,
                                                     double *__restrict__ b, double *__restrict__ x, SolverState *st, double eps,
                                                     long long maxit, long long res_cap) {
-  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) { b[i] = b_in[i]; x[i] = x_in[i]; }
+  int nz = 0;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    const double xi = x_in[i];
+    b[i] = b_in[i]; x[i] = xi;
+    nz |= xi != 0.0;   // NaN counts as non-zero
+  }
+  // x0_zero was left at 1 by the previous solve's k_solve_end (0 after allocation): it survives only if every entry is 0
+  if (__syncthreads_or(nz) && threadIdx.x == 0) st->x0_zero = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) { st->eps = eps; st->maxit = maxit; st->res_cap = res_cap; }
 }
 // out: x -> caller's vector (device), `it` / done / overflow and the first min(it, ncap) residual norms -> pinned host memory.
 __global__ __launch_bounds__(NT) void k_solve_end(int n, const SolverState *st, int fold, const double *__restrict__ x,
                                                   double *__restrict__ x_out, const double *__restrict__ res_norm,
-                                                  double *__restrict__ res_stage, long long ncap, PinnedFlags *flags) {
+                                                  double *__restrict__ res_stage, long long ncap, PinnedFlags *flags,
+                                                  int *x0_zero) {
   const long long it = fold ? st->it_nxt : st->it;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *x0_zero = 1;  // "assume zero" for the next solve's k_solve_begin to refute
   for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) x_out[i] = x[i];
   if (res_stage) {
     const long long m = it < ncap ? it : ncap;

@@ -29,6 +29,9 @@ struct DenseBlockOp;
 struct Operator {
   mi_ctx_s *ctx;
   int64_t n;  // operator is n x n on the Γ (or full) vector space
+  // Set by a solver around the `A*x0` of its set-up: device flag "x0 is identically zero" (the result is then +0
+  // without streaming A). Operators that cannot use it ignore it.
+  const int *zero_hint = nullptr;
   Operator(mi_ctx_s *c, int64_t n_) : ctx(c), n(n_) {}
   virtual ~Operator() = default;
   // Enqueue y = Op(x) on ctx->stream; x, y are device pointers, x != y.
@@ -351,7 +354,8 @@ struct DenseBlockOp : Operator {
   }
   void gemv(const double *x, const int *done) {
     if (!ntiles) return;
-#define MI_GEMV(R, S, V) hipLaunchKernelGGL((k_gemv_batched<R, S, V>), dim3(ntiles), dim3(64 * V), 0, ctx->stream, meta, x, yslots.p, done)
+    const int *zx = zero_hint;
+#define MI_GEMV(R, S, V) hipLaunchKernelGGL((k_gemv_batched<R, S, V>), dim3(ntiles), dim3(64 * V), 0, ctx->stream, meta, x, yslots.p, done, zx)
 #define MI_GEMV_R(S, V) do { if (rpw == 1) MI_GEMV(1, S, V); else if (rpw == 2) MI_GEMV(2, S, V); else MI_GEMV(4, S, V); } while (0)
     if (waves == 16)     { if (scale) MI_GEMV_R(true, 16); else MI_GEMV_R(false, 16); }
     else if (waves == 8) { if (scale) MI_GEMV_R(true, 8); else MI_GEMV_R(false, 8); }

@@ -303,8 +303,14 @@ struct Krylov {
   // eps / maxit / res_cap are read from the state block (uploaded by solve()), so this is graph-replayable.
   void setup_tail() {
     const int pre = M != nullptr;
+    struct Hint {  // `A*x0` may skip streaming A when the device flag says x0 == 0 (k_solve_begin)
+      Operator *op;
+      Hint(Operator *o, const int *flag) : op(o) { op->zero_hint = flag; }
+      ~Hint() { op->zero_hint = nullptr; }
+    };
     if (fold) {
-      const AsmView vAp = A->apply_view(ws.x, ws.Ap, nullptr);
+      AsmView vAp;
+      { Hint h(A, &ws.st->x0_zero); vAp = A->apply_view(ws.x, ws.Ap, nullptr); }
 #define MI_CALL(E) hipLaunchKernelGGL((k_fused_residual<E, true>), dim3(1), dim3(NTF), 0, s, n, ws.st, vAp, ws.b, ws.r)
       MI_EPT_DISPATCH(MI_CALL);
 #undef MI_CALL
@@ -312,7 +318,8 @@ struct Krylov {
       return;
     }
     if (fused && nvec == 0) {
-      const AsmView vAp = A->apply_view(ws.x, ws.Ap, nullptr);
+      AsmView vAp;
+      { Hint h(A, &ws.st->x0_zero); vAp = A->apply_view(ws.x, ws.Ap, nullptr); }
 #define MI_CALL(E) hipLaunchKernelGGL((k_fused_residual<E, false>), dim3(1), dim3(NTF), 0, s, n, ws.st, vAp, ws.b, ws.r)
       MI_EPT_DISPATCH(MI_CALL);
 #undef MI_CALL
@@ -323,7 +330,7 @@ struct Krylov {
       MI_HIP(hipGetLastError());
       return;
     }
-    A->apply(ws.x, ws.Ap, nullptr);
+    { Hint h(A, nvec == 0 ? &ws.st->x0_zero : nullptr); A->apply(ws.x, ws.Ap, nullptr); }  // deflated: x0 was updated by W*mu
     hipLaunchKernelGGL(k_residual, dim3(g), dim3(NT), 0, s, n, ws.b, ws.Ap, ws.r, ws.part_rr, ws.part_bb);
     const double *zz = ws.r;
     if (pre) {
@@ -421,7 +428,7 @@ struct Krylov {
     const bool spec_res = res_host && ncap > 0 && ncap <= RES_STAGE;
     auto enqueue_results = [&](int slot) {
       hipLaunchKernelGGL(k_solve_end, dim3(g), dim3(NT), 0, s, n, ws.st, (int)fold, ws.x, x_io, ws.res_norm.p,
-                         spec_res ? ws.res_stage : (double *)nullptr, (long long)ncap, &ws.flags[slot]);
+                         spec_res ? ws.res_stage : (double *)nullptr, (long long)ncap, &ws.flags[slot], &ws.st->x0_zero);
       MI_HIP(hipGetLastError());
     };
     if (use_graph) {

@@ -468,3 +468,39 @@ def test_res_capacity_and_borrowed_stream(pkg, ctx, micro):
     assert L.mi_ctx_set_stream(c3._h, None) == 0                               # back to the context's own stream
     again = api.pcg(S, b, np.zeros(n), M)
     assert np.array_equal(again[0], ref[0])
+
+
+def test_initial_guess_zero_shortcut_and_nonzero_guesses(pkg, ctx, orc, ragged):
+    """The set-up `r = b - A*x0` skips streaming A when x0 is identically zero (device flag set by the solve's entry
+    kernel). Alternate zero / non-zero / signed-zero / partly-zero guesses on the same operators: every solve must match
+    the oracle from the same guess — a stale flag would show as a wrong first residual."""
+    api = pkg.api
+    P = ragged
+    S, M = gpu_ops(pkg, ctx, P)
+    So, Mo = orc_ops(orc, P)
+    n, b = P.sub.n_Γ, P.b_schur
+    rng = np.random.default_rng(12)
+    part = np.zeros(n); part[n // 2] = 1e-300
+    guesses = [np.zeros(n), rng.standard_normal(n), np.zeros(n), -np.zeros(n), part, np.zeros(n), rng.standard_normal(n)]
+    for x0 in guesses:
+        for solver, osolver, args, oargs in ((api.pcg, orc.pcg, (M,), (Mo,)), (api.cg, orc.cg, (), ())):
+            got = solver(S, b, x0.copy(), *args)
+            want = osolver(So, b, x0.copy(), *oargs)
+            assert np.isclose(got[2][0], want[2][0], rtol=1e-12), "first residual: wrong x0 handling"
+            if not x0.any() or max(got[1], want[1]) > TIGHT_PREFIX:
+                assert_history(got, want, apply=So, b=b)
+                continue
+            # a random guess makes res_1 ~ 1e3 ||b||: the solve runs nine orders down from res_1 and the last entries sit
+            # at the floor of assert_history's bar (|Δ| ~ 1e-12 res_1); hold `it`, the history to 1e-6 (+1e-11 res_1)
+            # and the true residual instead
+            assert abs(got[1] - want[1]) <= max(1, want[1] // 50)
+            m = min(got[1], want[1])
+            assert np.allclose(got[2][:m], want[2][:m], rtol=1e-6, atol=1e-11 * want[2][0])
+            assert np.linalg.norm(b - So(got[0])) <= 2.0 * max(got[2][-1], 1e-7 * np.linalg.norm(b))
+    import torch
+    bt = torch.from_numpy(b).cuda()
+    for x0 in guesses[:3]:
+        xt = torch.from_numpy(x0.copy()).cuda()
+        got = api.pcg(S, bt, xt, M)
+        want = orc.pcg(So, b, x0.copy(), Mo)
+        assert got[1] == want[1] and np.isclose(got[2][0], want[2][0], rtol=1e-12)

@@ -129,9 +129,7 @@ __global__ __launch_bounds__(NT) void k_project_r(int n, double *__restrict__ r,
   __shared__ double sm[NT / 64 + 1];
   double srr = 0.0;
   for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
-    double wm = 0.0;
-    for (int k = 0; k < nvec; ++k) wm += W[(long long)k * n + i] * mu[k];
-    const double ri = r[i] - wm;
+    const double ri = r[i] - w_times_mu(W, n, i, mu, nvec);
     r[i] = ri;
     srr += ri * ri;
   }

@@ -72,7 +72,7 @@ struct EigKrylov {
   // The `if ivec == spdim` block (eigcg.jl:87-109 / 232-263; defcg.jl:185-210 / 421-442), after the iteration ran.
   void restart(const Snapshot &h) {
     if (kind == EIGPCG) {
-      for (int j = 0; j < spdim; ++j) k.A->apply(ws.eV.p + (size_t)j * n, ws.eAV.p + (size_t)j * n, nullptr);  // AV[:, j] = A * V[:, j]
+      k.A->apply_multi(ws.eV.p, n, spdim, ws.eAV.p, n);                     // AV[:, j] = A * V[:, j]
       hipLaunchKernelGGL(k_gram_rect, dim3(spdim, spdim), dim3(NT), 0, s, n, ws.eV.p, ws.eAV.p, ws.eT.p, spdim);  // VtAV .= V'AV
       MI_HIP(hipGetLastError());
     } else if (deflated && first_restart) {

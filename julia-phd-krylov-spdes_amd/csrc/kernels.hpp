@@ -38,39 +38,24 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;  // lane 0 holds the sum
 }
-// Deterministic workgroup sum, result broadcast to all NT threads. `sm` has NT/64 + 1 doubles.
-__device__ __forceinline__ double block_sum(double v, double *sm) {
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) sm[w] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int i = 0; i < NT / 64; ++i) t += sm[i];
-    sm[NT / 64] = t;
-  }
-  __syncthreads();
-  const double t = sm[NT / 64];
-  __syncthreads();
-  return t;
-}
-// The same for a workgroup of NTH threads (the GEMV kernels run with 256 or 512).
+// Deterministic workgroup sum, result broadcast to all threads: per-wave shuffle tree, the NTH/64 wave results through
+// LDS, then the same shuffle tree over them in every wave (no serial chain). `sm` has NTH/64 doubles (callers size it
+// NTH/64 + 1); the trailing barrier lets the next call reuse it.
 template <int NTH>
 __device__ __forceinline__ double block_sum_t(double v, double *sm) {
+  constexpr int NW = NTH / 64;
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) sm[w] = v;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int i = 0; i < NTH / 64; ++i) t += sm[i];
-    sm[NTH / 64] = t;
-  }
-  __syncthreads();
-  const double t = sm[NTH / 64];
+  double t = lane < NW ? sm[lane] : 0.0;
+#pragma unroll
+  for (int off = NW / 2; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  t = __shfl(t, 0, 64);
   __syncthreads();
   return t;
 }
+__device__ __forceinline__ double block_sum(double v, double *sm) { return block_sum_t<NT>(v, sm); }
 // Two workgroup sums with ONE barrier: per-wave shuffle trees, then every wave reduces the NTH/64 wave results with a
 // second shuffle tree (no serial LDS chain, no second barrier). Fixed tree: deterministic, identical in every workgroup.
 // `sm` has 2*(NTH/64) doubles and must not be reused before the next barrier.
@@ -96,6 +81,26 @@ __device__ __forceinline__ double sum_partials(const double *part, int g, double
   double v = 0.0;
   for (int i = threadIdx.x; i < g; i += NT) v += part[i];
   return block_sum(v, sm);
+}
+
+// (W*mu)[i] in column order (wm += W[i,k]*mu[k], k ascending — the order of a column-axpy gemv), with the loads of
+// eight columns issued together: a plain runtime loop serialises one memory round trip per column.
+__device__ __forceinline__ double w_times_mu(const double *__restrict__ W, long long n, long long i,
+                                             const double *__restrict__ mu, int nvec) {
+  double wm = 0.0;
+  for (int q0 = 0; q0 < nvec; q0 += 8) {
+    double w[8], m[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = q0 + u < nvec;
+      w[u] = ok ? W[(long long)(q0 + u) * n + i] : 0.0;
+      m[u] = ok ? mu[q0 + u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (q0 + u < nvec) wm += w[u] * m[u];
+  }
+  return wm;
 }
 
 // ------------------------------------------------------------------ BLAS-1 building blocks
@@ -491,6 +496,87 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_batched(DenseMeta m, const 
   }
 }
 
+// The same GEMV for KV operand vectors at once: S_d is streamed ONCE for up to KV columns of X (`WtA[i,:] = A*W[:,i]`
+// of the deflated solvers, defcg.jl:41-44 / 261-264; `AV[:, j] = A*V[:, j]` of eigpcg's restart, eigcg.jl:233-240) instead of once
+// per column. Per (row, vector) the products are accumulated in the order of k_gemv_batched: results are bit-identical
+// to KV single applies. X is column-major with leading dimension ldx; vector v writes its slot table at v*slot_stride.
+template <int RPW, int KV, bool SCALE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_gemv_multi(DenseMeta m, const double *__restrict__ X, long long ldx, int kv,
+                                                           double *__restrict__ yslots, long long slot_stride) {
+  constexpr int NTH = 64 * WAVES;
+  __shared__ __attribute__((aligned(16))) double xs[KV][GEMV_PANEL];
+  const GemvTile t = m.tiles[blockIdx.x];
+  const int off = t.loc_off, n = t.n, lane = threadIdx.x & 63;
+  const int row_base = t.row0 + (threadIdx.x >> 6) * RPW;
+  const double *rowp[RPW];
+  double acc[RPW][KV];
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    rowp[k] = m.M + t.mat_off + (long long)min(row_base + k, n - 1) * t.ld;
+#pragma unroll
+    for (int v = 0; v < KV; ++v) acc[k][v] = 0.0;
+  }
+  for (int c0 = 0; c0 < t.ld; c0 += GEMV_PANEL) {
+    const int pw = min(GEMV_PANEL, t.ld - c0);
+    if (c0) __syncthreads();
+    for (int l = threadIdx.x; l < pw; l += NTH) {
+      const int j = c0 + l;
+      const int gi = j < n ? m.gidx[off + j] : -1;
+      const double cn = (SCALE && j < n) ? m.cnt[off + j] : 1.0;
+#pragma unroll
+      for (int v = 0; v < KV; ++v) {
+        double xv = 0.0;
+        if (gi >= 0 && v < kv) {
+          xv = X[(long long)v * ldx + gi];
+          if (SCALE) xv = xv / cn;
+        }
+        xs[v][l] = xv;
+      }
+    }
+    __syncthreads();
+    double2 buf[RPW][GU];
+    for (int cb = 0; cb < pw; cb += 128 * GU) {
+      gemv_load_group<RPW>(buf, rowp, c0, cb, pw, lane);
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int c = cb + u * 128 + lane * 2;
+        if (c < pw) {
+#pragma unroll
+          for (int v = 0; v < KV; ++v) {
+            const double2 xv = *reinterpret_cast<const double2 *>(&xs[v][c]);
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+              acc[k][v] += buf[k][u].x * xv.x;
+              acc[k][v] += buf[k][u].y * xv.y;
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int r = row_base + k;
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
+      const double sum = wave_sum(acc[k][v]);
+      if (lane == 0 && r < n && v < kv)
+        yslots[(long long)v * slot_stride + m.out_pos[off + r]] = SCALE ? sum / m.cnt[off + r] : sum;
+    }
+  }
+}
+// Γ-sum of the slot tables of k_gemv_multi: grid (x, kv); vector v -> Y[:, v] (leading dimension ldy)
+__global__ __launch_bounds__(NT) void k_assemble_slots_multi(int n, int width, const double *__restrict__ yslots,
+                                                             long long slot_stride, double *__restrict__ Y, long long ldy) {
+  const double *ys = yslots + (long long)blockIdx.y * slot_stride;
+  double *y = Y + (long long)blockIdx.y * ldy;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    double s = 0.0;
+    for (int j = 0; j < width; ++j) s += ys[(long long)i * width + j];
+    y[i] = s;
+  }
+}
+
 // ------------------------------------------------------------------ PCG folded into the two GEMVs (2 launches / iteration)
 // For pcg(S, b, x, ΠSnn) with both operators dense and built on the same subdomain maps, the vector
 // work of an iteration is folded into the prologue/epilogue of the two GEMV launches:
@@ -856,9 +942,7 @@ __global__ __launch_bounds__(NT) void k_update_p(int n, SolverState *st, const d
   for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
     double v = beta * p[i] + z[i];     // axpby!(1, z, beta, p)
     if (nvec > 0) {
-      double wm = 0.0;                 // (W*mu)[i], column-axpy order
-      for (int k = 0; k < nvec; ++k) wm += W[(long long)k * n + i] * mu[k];
-      v = v - wm;
+      v = v - w_times_mu(W, n, i, mu, nvec);   // (W*mu)[i], column-axpy order
     }
     p[i] = v;
   }
@@ -930,21 +1014,7 @@ __device__ __forceinline__ double view_load(const AsmView &v, int e) {
   return s;
 }
 // Deterministic sum over the 1024-thread workgroup, broadcast. `sm` has NTF/64 + 1 doubles.
-__device__ __forceinline__ double block_sum_f(double v, double *sm) {
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) sm[w] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int i = 0; i < NTF / 64; ++i) t += sm[i];
-    sm[NTF / 64] = t;
-  }
-  __syncthreads();
-  const double t = sm[NTF / 64];
-  __syncthreads();
-  return t;
-}
+__device__ __forceinline__ double block_sum_f(double v, double *sm) { return block_sum_t<NTF>(v, sm); }
 // Ap = view; d = p'Ap; alpha = num/d; x += alpha p; r -= alpha Ap; r'r   (cg.jl:36-43 / 93-99)
 template <int EPT>
 __global__ __launch_bounds__(NTF) void k_fused_xr(int n, SolverState *st, AsmView vAp, const double *__restrict__ p,
@@ -1015,6 +1085,13 @@ __global__ __launch_bounds__(NTF) void k_fused_p(int n, SolverState *st, AsmView
   if (st->done) return;  // written only by thread 0 at the very end, behind the barriers below
   __shared__ double sm[NTF / 64 + 1];
   __shared__ double mu_s[64];
+  __shared__ double lu_s[64 * 64];  // the factors in LDS: the substitution is a chain of 3*nvec dependent steps, and a
+  __shared__ int piv_s[64];         // global load inside every step costs a memory round trip each
+  const bool wave_lu = nvec > 0 && LU;
+  if (wave_lu) {
+    for (int i = threadIdx.x; i < nvec * nvec; i += NTF) lu_s[i] = LU[i];
+    if ((int)threadIdx.x < nvec) piv_s[threadIdx.x] = piv[threadIdx.x];
+  }
   const double rr = st->rTr;
   const double old = precond ? st->rTz_prev : st->rTr_prev;
   const double tol = st->tol;
@@ -1031,24 +1108,44 @@ __global__ __launch_bounds__(NTF) void k_fused_p(int n, SolverState *st, AsmView
       if (precond) s += r[e] * ze[k];
     }
   }
-  if (nvec > 0 && LU && threadIdx.x < 64) {
-    const double m = wave_lu_solve(nvec, LU, piv, threadIdx.x < (unsigned)nvec ? rhs[threadIdx.x] : 0.0);
-    mu_s[threadIdx.x] = m;
+  if (wave_lu) {
+    const double rv = threadIdx.x < (unsigned)nvec ? rhs[threadIdx.x] : 0.0;
+    __syncthreads();  // lu_s, piv_s
+    if (threadIdx.x < 64) mu_s[threadIdx.x] = wave_lu_solve(nvec, lu_s, piv_s, rv);
   }
   const double rz = precond ? block_sum_f(s, sm) : rr;
   if (!precond) __syncthreads();  // mu_s visible (block_sum_f has barriers of its own)
   double beta = 1. / old;
   beta *= rz;
+  double wm[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) wm[k] = 0.0;
+  if (nvec > 0) {  // (W*mu)[e] in column order; the loads of 8 columns x EPT elements go out together (one round trip per 8 columns)
+    const double *mup = LU ? mu_s : mu;
+    constexpr int QB = EPT >= 8 ? 4 : 8;  // EPT*QB doubles in flight per thread (<= 64 VGPRs)
+    for (int q0 = 0; q0 < nvec; q0 += QB) {
+      double w[EPT][QB];
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int e = k * NTF + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < QB; ++u) w[k][u] = (e < n && q0 + u < nvec) ? W[(long long)(q0 + u) * n + e] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < QB; ++u)
+        if (q0 + u < nvec) {
+          const double m = mup[q0 + u];
+#pragma unroll
+          for (int k = 0; k < EPT; ++k) wm[k] += w[k][u] * m;
+        }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int e = k * NTF + threadIdx.x;
     if (e < n) {
       double v = beta * pe[k] + ze[k];
-      if (nvec > 0) {
-        double wm = 0.0;
-        for (int q = 0; q < nvec; ++q) wm += W[(long long)q * n + e] * (LU ? mu_s[q] : mu[q]);
-        v = v - wm;
-      }
+      if (nvec > 0) v = v - wm[k];
       p[e] = v;
     }
   }
@@ -1185,11 +1282,7 @@ __global__ __launch_bounds__(NT) void k_init_p(int n, const double *__restrict__
                                                const double *__restrict__ W, const double *__restrict__ mu, int nvec) {
   for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
     double v = z[i];
-    if (nvec > 0) {
-      double wm = 0.0;
-      for (int k = 0; k < nvec; ++k) wm += W[(long long)k * n + i] * mu[k];
-      v = v - wm;
-    }
+    if (nvec > 0) v = v - w_times_mu(W, n, i, mu, nvec);
     p[i] = v;
   }
 }
@@ -1197,9 +1290,7 @@ __global__ __launch_bounds__(NT) void k_init_p(int n, const double *__restrict__
 __global__ __launch_bounds__(NT) void k_add_Wmu(int n, double *__restrict__ x, const double *__restrict__ W,
                                                 const double *__restrict__ mu, int nvec) {
   for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
-    double wm = 0.0;
-    for (int k = 0; k < nvec; ++k) wm += W[(long long)k * n + i] * mu[k];
-    x[i] = x[i] + wm;
+    x[i] = x[i] + w_times_mu(W, n, i, mu, nvec);
   }
 }
 // part[v*gx + g] = partial of V[:,v] . z   (V = AW for `WtA*z`, V = W for `W'r`); grid (gx, nvec)
@@ -1214,15 +1305,25 @@ __global__ __launch_bounds__(NT) void k_multi_dot_partial(int n, const double *_
   s = block_sum(s, sm);
   if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
-// part[v] = V[:,v] . z with z given as a view (small systems: one workgroup per vector); grid (nvec)
-__global__ __launch_bounds__(NT) void k_multi_dot_view(int n, const double *__restrict__ V, AsmView vz,
-                                                       double *__restrict__ part, const int *done) {
+// part[v] = V[:,v] . z with z given as a view (small systems: one 1024-thread workgroup per vector, all loads of a
+// thread issued together); grid (nvec)
+template <int EPT>
+__global__ __launch_bounds__(NTF) void k_multi_dot_view(int n, const double *__restrict__ V, AsmView vz,
+                                                        double *__restrict__ part, const int *done) {
   if (done && *done) return;
-  __shared__ double sm[NT / 64 + 1];
+  __shared__ double sm[NTF / 64 + 1];
   const double *v = V + (long long)blockIdx.x * n;
+  double a[EPT], b[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = k * NTF + threadIdx.x;
+    a[k] = b[k] = 0.0;
+    if (e < n) { a[k] = v[e]; b[k] = view_load(vz, e); }
+  }
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += NT) s += v[i] * view_load(vz, i);
-  s = block_sum(s, sm);
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) s += a[k] * b[k];
+  s = block_sum_f(s, sm);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 // C[i + j*nvec] = partial-free small gemm entry AW[:,i] . W[:,j]; grid (nvec, nvec), one workgroup each.
@@ -1243,6 +1344,19 @@ __global__ __launch_bounds__(64) void k_lu_solve(int nvec, const double *__restr
                                                  const int *done) {
   if (done && *done) return;
   extern __shared__ double bsh[];
+  if (nvec <= 64) {  // one wave, factors staged in LDS (launched with nvec + nvec*nvec + nvec/2 + 1 doubles of LDS)
+    double *lu_s = bsh + nvec;
+    int *piv_s = reinterpret_cast<int *>(lu_s + nvec * nvec);
+    for (int i = threadIdx.x; i < nvec * nvec; i += 64) lu_s[i] = LU[i];
+    if ((int)threadIdx.x < nvec) piv_s[threadIdx.x] = piv[threadIdx.x];
+    double s = 0.0;
+    if ((int)threadIdx.x < nvec)
+      for (int g = 0; g < gx; ++g) s += part[threadIdx.x * gx + g];
+    __syncthreads();
+    s = wave_lu_solve(nvec, lu_s, piv_s, s);
+    if ((int)threadIdx.x < nvec) mu[threadIdx.x] = s;
+    return;
+  }
   for (int v = threadIdx.x; v < nvec; v += 64) {
     double s = 0.0;
     for (int g = 0; g < gx; ++g) s += part[v * gx + g];

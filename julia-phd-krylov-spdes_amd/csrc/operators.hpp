@@ -47,6 +47,11 @@ struct Operator {
   virtual bool apply_dot(const double *x, double *y, const double *w, const double **part, int *count, const int *done) {
     return false;
   }
+  // Y[:, v] = Op(X[:, v]) for v < k (column-major, leading dimensions ldx, ldy). Dense block operators stream their
+  // matrices once per group of columns; the default is k single applies.
+  virtual void apply_multi(const double *X, int64_t ldx, int k, double *Y, int64_t ldy) {
+    for (int v = 0; v < k; ++v) apply(X + (size_t)v * ldx, Y + (size_t)v * ldy, nullptr);
+  }
   virtual int diag_kind(const double **dinv) const { return 0; }
   virtual DenseBlockOp *as_dense() { return nullptr; }
   virtual bool graph_safe() const { return true; }  // false: apply synchronises with the host
@@ -372,6 +377,23 @@ struct DenseBlockOp : Operator {
     if (reduce_over_ranks) ctx->allreduce(y, (size_t)n);
   }
   DenseBlockOp *as_dense() override { return this; }
+  static constexpr int KV = 4;  // columns per pass of apply_multi (4 x 16 KiB of LDS for the operand panels)
+  DevBuf<double> yslots_multi;
+  void apply_multi(const double *X, int64_t ldx, int k, double *Y, int64_t ldy) override {
+    if (reduce_over_ranks || !ntiles || env_int("MI355_NO_MULTI", 0)) { Operator::apply_multi(X, ldx, k, Y, ldy); return; }
+    const long long stride = (long long)n * maps.slot_width + 4;
+    if (yslots_multi.n < (size_t)(stride * KV)) { yslots_multi.alloc((size_t)(stride * KV)); yslots_multi.zero(ctx->stream); }
+    for (int v0 = 0; v0 < k; v0 += KV) {
+      const int kv = std::min(KV, k - v0);
+      const double *Xv = X + (size_t)v0 * ldx;
+#define MI_GM(S) hipLaunchKernelGGL((k_gemv_multi<2, KV, S, 16>), dim3(ntiles), dim3(1024), 0, ctx->stream, meta, Xv, (long long)ldx, kv, yslots_multi.p, stride)
+      if (scale) MI_GM(true); else MI_GM(false);
+#undef MI_GM
+      hipLaunchKernelGGL(k_assemble_slots_multi, dim3(vec_grid(n), kv), dim3(NT), 0, ctx->stream, (int)n, maps.slot_width,
+                         yslots_multi.p, stride, Y + (size_t)v0 * ldy, (long long)ldy);
+    }
+    MI_HIP(hipGetLastError());
+  }
   // One launch of the folded PCG pair (kernels.hpp k_gemv_pcg); PHASE 1 on the ΠS operator, 0 on S.
   void gemv_pcg(int phase, const PcgFold &f) {
     if (!ntiles) return;

@@ -200,7 +200,8 @@ struct Krylov {
   void project(const double *V, const double *v, const int *dn) { project(V, v, dn, ws.LU.p, ws.piv.p, ws.mu.p); }
   void project(const double *V, const double *v, const int *dn, const double *LU, const int *piv, double *mu) {
     hipLaunchKernelGGL(k_multi_dot_partial, dim3(g, nvec), dim3(NT), 0, s, n, V, v, ws.part_mu.p, dn);
-    hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(64), sizeof(double) * nvec, s, nvec, LU, piv, ws.part_mu.p, g, mu, dn);
+    hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(64), sizeof(double) * (nvec <= 64 ? nvec + nvec * nvec + nvec / 2 + 1 : nvec), s, nvec, LU, piv,
+                       ws.part_mu.p, g, mu, dn);
     MI_HIP(hipGetLastError());
   }
   // Lanczos bookkeeping of the eigCG family for the iteration just enqueued (z: what p was updated with)
@@ -252,7 +253,9 @@ struct Krylov {
       if (pre) vz = M->apply_view(ws.r, ws.z, dn);                    // z .= M \ r, Γ-sum deferred
       const bool wave_lu = nvec > 0 && nvec <= 64;                    // mu solved inside k_fused_p by one wave
       if (wave_lu) {
-        hipLaunchKernelGGL(k_multi_dot_view, dim3(nvec), dim3(NT), 0, s, n, ws.AW.p, vz, ws.part_mu.p, dn);  // WtA * z
+#define MI_CALL(E) hipLaunchKernelGGL((k_multi_dot_view<E>), dim3(nvec), dim3(NTF), 0, s, n, ws.AW.p, vz, ws.part_mu.p, dn)
+        MI_EPT_DISPATCH(MI_CALL);                                     // WtA * z
+#undef MI_CALL
       } else if (nvec > 0) {
         if (vz.width) {  // materialise z for the generic projection kernels
           hipLaunchKernelGGL(k_assemble_slots, dim3(vec_grid(n)), dim3(NT), 0, s, n, vz.width, vz.src, ws.z, dn);
@@ -391,7 +394,7 @@ struct Krylov {
     MI_HIP(hipGetLastError());
     if (nvec > 0) {
       MI_HIP(hipMemcpyAsync(ws.W.p, W_in, vb * nvec, hipMemcpyDeviceToDevice, s));
-      for (int v = 0; v < nvec; ++v) A->apply(ws.W.p + (size_t)v * n, ws.AW.p + (size_t)v * n, nullptr);  // WtA[v,:] = A*W[:,v]
+      A->apply_multi(ws.W.p, n, nvec, ws.AW.p, n);                           // WtA[v,:] = A*W[:,v]
       hipLaunchKernelGGL(k_small_gram, dim3(nvec, nvec), dim3(NT), 0, s, n, ws.AW.p, ws.W.p, ws.gram.p, nvec);  // WtAW
       MI_HIP(hipGetLastError());
       factor(ws.gram.p, ws.LU, ws.piv, &gram_host, "WtAW");

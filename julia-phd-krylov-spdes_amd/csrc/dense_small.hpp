@@ -1,7 +1,7 @@
 // Host-side small dense linear algebra for the eigCG family's Ritz restarts (spdim <= a few hundred):
 // what the reference asks of LinearAlgebra there — eigvecs(Symmetric(T)), rank(Y), svd(Y).U, eigen(H)
-// (eigcg.jl:92-99, 244-253; defcg.jl:190-198, 426-435). Jacobi methods: no LAPACK is linked into this
-// library, the matrices are tiny, and Jacobi gives eigenvectors/singular vectors to high relative accuracy.
+// (eigcg.jl:92-99, 244-253; defcg.jl:190-198, 426-435). No LAPACK is linked into this library: symmetric eigenproblems
+// go through Householder tridiagonalisation + implicit QL (cyclic Jacobi as the fallback), the SVD through one-sided Jacobi.
 // All matrices are column-major.
 #pragma once
 #include <algorithm>
@@ -15,13 +15,9 @@ namespace dense {
 
 using Mat = std::vector<double>;
 
-// Eigen-decomposition of the symmetric matrix whose UPPER triangle is in `a` (n x n, leading dimension lda):
-// cyclic Jacobi; eigenvalues ascending in `vals`, eigenvectors in the columns of `vecs` (n x n).
-inline void sym_eig_upper(int n, const double *a, int lda, std::vector<double> &vals, Mat &vecs) {
-  Mat A((size_t)n * n);
-  for (int j = 0; j < n; ++j)
-    for (int i = 0; i <= j; ++i) A[i + (size_t)j * n] = A[j + (size_t)i * n] = a[i + (size_t)j * lda];
-  Mat V((size_t)n * n, 0.0);
+// Cyclic Jacobi on a full symmetric matrix A (n x n, overwritten); V receives the eigenvectors. Robust fallback.
+inline void jacobi_eig(int n, Mat &A, Mat &V) {
+  V.assign((size_t)n * n, 0.0);
   for (int i = 0; i < n; ++i) V[i + (size_t)i * n] = 1.0;
   for (int sweep = 0; sweep < 100; ++sweep) {
     double off = 0.0;
@@ -62,13 +58,135 @@ inline void sym_eig_upper(int n, const double *a, int lda, std::vector<double> &
       }
     if (!rotated) break;
   }
+}
+
+// Householder tridiagonalisation (the classical EISPACK tred2 scheme) of the full symmetric A (n x n, column-major,
+// overwritten by the accumulated orthogonal transformation Q, A = Q T Q'); d: diagonal of T, e: sub-diagonal (e[0] = 0).
+inline void householder_tridiag(int n, Mat &a, std::vector<double> &d, std::vector<double> &e) {
+  auto A = [&](int i, int j) -> double & { return a[i + (size_t)j * n]; };
+  d.assign(n, 0.0); e.assign(n, 0.0);
+  for (int i = n - 1; i >= 1; --i) {
+    const int l = i - 1;
+    double h = 0.0, scale = 0.0;
+    if (l > 0) {
+      for (int k = 0; k <= l; ++k) scale += std::fabs(A(i, k));
+      if (scale == 0.0) {
+        e[i] = A(i, l);
+      } else {
+        for (int k = 0; k <= l; ++k) { A(i, k) /= scale; h += A(i, k) * A(i, k); }
+        double f = A(i, l);
+        double g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
+        e[i] = scale * g;
+        h -= f * g;
+        A(i, l) = f - g;
+        f = 0.0;
+        for (int j = 0; j <= l; ++j) {
+          A(j, i) = A(i, j) / h;
+          g = 0.0;
+          for (int k = 0; k <= j; ++k) g += A(j, k) * A(i, k);
+          for (int k = j + 1; k <= l; ++k) g += A(k, j) * A(i, k);
+          e[j] = g / h;
+          f += e[j] * A(i, j);
+        }
+        const double hh = f / (h + h);
+        for (int j = 0; j <= l; ++j) {
+          f = A(i, j);
+          e[j] = g = e[j] - hh * f;
+          for (int k = 0; k <= j; ++k) A(j, k) -= f * e[k] + g * A(i, k);
+        }
+      }
+    } else {
+      e[i] = A(i, l);
+    }
+    d[i] = h;
+  }
+  d[0] = 0.0; e[0] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const int l = i - 1;
+    if (d[i] != 0.0) {
+      for (int j = 0; j <= l; ++j) {
+        double g = 0.0;
+        for (int k = 0; k <= l; ++k) g += A(i, k) * A(k, j);
+        for (int k = 0; k <= l; ++k) A(k, j) -= g * A(k, i);
+      }
+    }
+    d[i] = A(i, i);
+    A(i, i) = 1.0;
+    for (int j = 0; j <= l; ++j) A(j, i) = A(i, j) = 0.0;
+  }
+}
+
+// Implicit-shift QL on the tridiagonal (d, e) with the transformations accumulated into z (n x n, column-major; on entry
+// the Q of householder_tridiag). Returns false if an eigenvalue needs more than 60 iterations.
+inline bool tridiag_ql(int n, std::vector<double> &d, std::vector<double> &e, Mat &z) {
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) {
+        const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+        if (std::fabs(e[m]) + dd == dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 60) return false;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = s * e[i];
+          const double b = c * e[i];
+          r = std::hypot(f, g);
+          e[i + 1] = r;
+          if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
+          s = f / r; c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          p = s * r;
+          d[i + 1] = g + p;
+          g = c * r - b;
+          for (int k = 0; k < n; ++k) {
+            f = z[k + (size_t)(i + 1) * n];
+            z[k + (size_t)(i + 1) * n] = s * z[k + (size_t)i * n] + c * f;
+            z[k + (size_t)i * n] = c * z[k + (size_t)i * n] - s * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p; e[l] = g; e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  return true;
+}
+
+// Eigen-decomposition of the symmetric matrix whose UPPER triangle is in `a` (n x n, leading dimension lda):
+// Householder tridiagonalisation + implicit QL (Jacobi if QL does not converge); eigenvalues ascending in `vals`,
+// eigenvectors in the columns of `vecs` (n x n).
+inline void sym_eig_upper(int n, const double *a, int lda, std::vector<double> &vals, Mat &vecs) {
+  Mat A((size_t)n * n);
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i <= j; ++i) A[i + (size_t)j * n] = A[j + (size_t)i * n] = a[i + (size_t)j * lda];
+  std::vector<double> d, e;
+  Mat V = A;
+  bool ok = n > 0;
+  if (n > 0) {
+    householder_tridiag(n, V, d, e);
+    ok = tridiag_ql(n, d, e, V);
+  }
+  if (!ok && n > 0) {
+    jacobi_eig(n, A, V);
+    d.resize(n);
+    for (int i = 0; i < n; ++i) d[i] = A[i + (size_t)i * n];
+  }
   std::vector<int> order(n);
   std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return A[x + (size_t)x * n] < A[y + (size_t)y * n]; });
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return d[x] < d[y]; });
   vals.resize(n);
   vecs.assign((size_t)n * n, 0.0);
   for (int j = 0; j < n; ++j) {
-    vals[j] = A[order[j] + (size_t)order[j] * n];
+    vals[j] = d[order[j]];
     std::copy(V.begin() + (size_t)order[j] * n, V.begin() + (size_t)(order[j] + 1) * n, vecs.begin() + (size_t)j * n);
   }
 }

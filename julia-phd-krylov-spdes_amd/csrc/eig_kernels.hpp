@@ -19,14 +19,15 @@ struct EigState {
 // V[:, col] = z / sqrt(rTz)  (pcg variants)  or  r / res_norm[it]  (cg variants); after a restart also
 // tvec = -beta * Ap (eigcg.jl:108 / 262). Scalars come from the state block. Launched eagerly by the host
 // (set-up and restarts), never inside a graph.
-__global__ __launch_bounds__(NT) void k_eig_seed(int n, const SolverState *st, int pre, const double *__restrict__ z,
-                                                 double *__restrict__ vcol, double *__restrict__ tvec,
-                                                 const double *__restrict__ Ap) {
+// z and Ap are "views" (kernels.hpp AsmView): plain vectors, or the contribution slots of the dense operators whose
+// Γ-sum is taken on the fly (the fused loop never materialises z and Ap).
+__global__ __launch_bounds__(NT) void k_eig_seed(int n, const SolverState *st, int pre, AsmView z, double *__restrict__ vcol,
+                                                 double *__restrict__ tvec, AsmView Ap) {
   const double scale = sqrt(pre ? st->rTz : st->rTr);
   const double mbeta = -st->beta;
   for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
-    vcol[i] = z[i] / scale;
-    if (tvec) tvec[i] = mbeta * Ap[i];
+    if (vcol) vcol[i] = view_load(z, i) / scale;
+    if (tvec) tvec[i] = mbeta * view_load(Ap, i);
   }
 }
 
@@ -35,8 +36,7 @@ __global__ __launch_bounds__(NT) void k_eig_seed(int n, const SolverState *st, i
 //   if just_restarted: tvec .+= Ap       (:80 / 226)
 //   if ivec != spdim:  V[:, ivec+1] = z/sqrt(rTz) | r/res_norm[it]   (:112 / 265; defcg.jl:213 / 446)
 __global__ __launch_bounds__(NT) void k_eig_vec(int n, const SolverState *st, const EigState *es, int pre, int spdim,
-                                                const double *__restrict__ z, const double *__restrict__ Ap,
-                                                double *__restrict__ V, double *__restrict__ tvec) {
+                                                AsmView z, AsmView Ap, double *__restrict__ V, double *__restrict__ tvec) {
   if (st->it <= es->rec_it) return;
   const int ivec = es->ivec, jr = es->just_restarted;
   const bool last = ivec == spdim - 1;
@@ -46,12 +46,12 @@ __global__ __launch_bounds__(NT) void k_eig_vec(int n, const SolverState *st, co
   for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
     if (tvec && (last || jr)) {
       double t = tvec[i];
-      const double a = Ap[i];
+      const double a = view_load(Ap, i);
       if (last) t = t - beta * a;
       if (jr) t = t + a;
       tvec[i] = t;
     }
-    if (!last) vnew[i] = z[i] / scale;
+    if (!last) vnew[i] = view_load(z, i) / scale;
   }
 }
 

@@ -30,7 +30,8 @@ struct EigKrylov {
   bool first_restart = true;
 
   EigKrylov(mi_ctx_s *c, Operator *A, Operator *M, EigKind kind_, int nvec_, int spdim_)
-      : k(c, A, M, (kind_ == EIGDEFCG || kind_ == EIGDEFPCG) ? nvec_ : 0, /*generic=*/true), kind(kind_), nvec(nvec_),
+      : k(c, A, M, (kind_ == EIGDEFCG || kind_ == EIGDEFPCG) ? nvec_ : 0, /*generic=*/kind_ == EIGDEFPCG, /*allow_fold=*/false),
+        kind(kind_), nvec(nvec_),
         spdim(spdim_), pre(M != nullptr), deflated(kind_ == EIGDEFCG || kind_ == EIGDEFPCG), has_tvec(!deflated), ws(k.ws),
         s(c->stream), n(k.n), g(k.g) {}
 
@@ -51,7 +52,6 @@ struct EigKrylov {
     MI_HIP(hipStreamSynchronize(s));
     return T;
   }
-  const double *zvec() const { return pre ? ws.z : ws.r; }
 
   // VtAV[1:nvec, nvec+1:m] = WtA * V[:, nvec+1:m]  (defcg.jl:186-189 / 422-425, 455-457)
   void deflated_block(int m) {
@@ -71,6 +71,11 @@ struct EigKrylov {
 
   // The `if ivec == spdim` block (eigcg.jl:87-109 / 232-263; defcg.jl:185-210 / 421-442), after the iteration ran.
   void restart(const Snapshot &h) {
+    if (has_tvec) {  // tvec .= -beta*Ap first: the A-applies below may reuse the slots the Ap view points at
+      hipLaunchKernelGGL(k_eig_seed, dim3(g), dim3(NT), 0, s, n, ws.st, (int)pre, k.z_view(), (double *)nullptr, ws.etvec.p,
+                         k.Ap_view());
+      MI_HIP(hipGetLastError());
+    }
     if (kind == EIGPCG) {
       k.A->apply_multi(ws.eV.p, n, spdim, ws.eAV.p, n);                     // AV[:, j] = A * V[:, j]
       hipLaunchKernelGGL(k_gram_rect, dim3(spdim, spdim), dim3(NT), 0, s, n, ws.eV.p, ws.eAV.p, ws.eT.p, spdim);  // VtAV .= V'AV
@@ -84,8 +89,8 @@ struct EigKrylov {
     if (R.nev + 1 > spdim) raise(MI_ERR_BOUNDS, "eig restart: nev + 1 = %d exceeds spdim = %d (BoundsError)", R.nev + 1, spdim);
     rotate(R, spdim);
     const int ivec = R.nev;  // 0-based column of the new Lanczos vector
-    hipLaunchKernelGGL(k_eig_seed, dim3(g), dim3(NT), 0, s, n, ws.st, (int)pre, zvec(), ws.eV.p + (size_t)ivec * n,
-                       has_tvec ? ws.etvec.p : (double *)nullptr, ws.Ap);
+    hipLaunchKernelGGL(k_eig_seed, dim3(g), dim3(NT), 0, s, n, ws.st, (int)pre, k.z_view(), ws.eV.p + (size_t)ivec * n,
+                       (double *)nullptr, k.Ap_view());
     MI_HIP(hipGetLastError());
     std::fill(T.begin(), T.end(), 0.0);
     for (int j = 0; j < R.nev; ++j) T[j + (size_t)j * spdim] = R.vals[j];
@@ -144,8 +149,8 @@ struct EigKrylov {
     }
     ws.eT.upload(T.data(), T.size(), s);
     MI_HIP(hipMemsetAsync(ws.etvec.p, 0, sizeof(double) * (size_t)n, s));
-    hipLaunchKernelGGL(k_eig_seed, dim3(g), dim3(NT), 0, s, n, ws.st, (int)pre, zvec(), ws.eV.p + (size_t)ivec0 * n,
-                       (double *)nullptr, ws.Ap);
+    hipLaunchKernelGGL(k_eig_seed, dim3(g), dim3(NT), 0, s, n, ws.st, (int)pre, k.z_view(), ws.eV.p + (size_t)ivec0 * n,
+                       (double *)nullptr, k.Ap_view());
     MI_HIP(hipGetLastError());
     EigState es0{};
     es0.rec_it = 1;

@@ -42,6 +42,8 @@ struct Operator {
     apply(x, y, done);
     return AsmView{y, 0};
   }
+  // The view apply_view(x, y, ...) returns, without launching anything
+  virtual AsmView view_of(double *y) { return AsmView{y, 0}; }
   // Optional fusions the solver asks for: y = Op(x) together with per-workgroup partials of w'y; and, for a
   // preconditioner, "I am diagonal" (1: identity, 2: Jacobi with `*dinv`) so that z = M \ r is folded into the r-update.
   virtual bool apply_dot(const double *x, double *y, const double *w, const double **part, int *count, const int *done) {
@@ -412,6 +414,9 @@ struct DenseBlockOp : Operator {
   bool same_maps(const DenseBlockOp &o) const {
     return n == o.n && rpw == o.rpw && waves == o.waves && ntiles == o.ntiles && maps.slot_width == o.maps.slot_width &&
            maps.nd == o.maps.nd && maps.gidx_h == o.maps.gidx_h;
+  }
+  AsmView view_of(double *) override {
+    return reduce_over_ranks ? AsmView{yslots_all.p, maps.slot_width} : AsmView{yslots.p, maps.slot_width};
   }
   AsmView apply_view(const double *x, double *y, const int *done) override {
     gemv(x, done);

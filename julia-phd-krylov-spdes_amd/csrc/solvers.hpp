@@ -161,10 +161,10 @@ struct Krylov {
   } eig;
   std::vector<double> gram_host;  // WtAW as computed (before LU), kept for VtAV[1:nvec,1:nvec] (defcg.jl:158 / 391)
 
-  Krylov(mi_ctx_s *c, Operator *A_, Operator *M_, int nvec_, bool generic = false)
+  Krylov(mi_ctx_s *c, Operator *A_, Operator *M_, int nvec_, bool generic = false, bool allow_fold = true)
       : ctx(c), A(A_), M(M_), ws(workspace(c, A_->n)), nvec(nvec_), n((int)A_->n), g(ws.g), s(c->stream),
         fused(!generic && A_->n <= FUSED_MAX_N && !env_int("MI355_NO_FUSED", 0)), fold(false) {
-    if (fused && M && nvec == 0 && !env_int("MI355_NO_FOLD", 0)) {
+    if (fused && allow_fold && M && nvec == 0 && !env_int("MI355_NO_FOLD", 0)) {
       Ad = A->as_dense(); Md = M->as_dense();
       fold = Ad && Md && !Ad->reduce_over_ranks && !Md->reduce_over_ranks &&
              !Ad->scale && Md->scale && Ad->same_maps(*Md) && Ad->ntiles > 0 && Ad->max_ld <= GEMV_PANEL && Ad->maps.slot_width <= 4 &&
@@ -204,11 +204,18 @@ struct Krylov {
                        ws.part_mu.p, g, mu, dn);
     MI_HIP(hipGetLastError());
   }
-  // Lanczos bookkeeping of the eigCG family for the iteration just enqueued (z: what p was updated with)
-  void eig_record(const double *zz) {
+  // z (what p is updated with) and Ap of the current iteration as the loop in use leaves them: slot views in the fused
+  // loop, plain vectors in the multi-workgroup one
+  AsmView z_view() const {
+    if (!M) return AsmView{ws.r, 0};
+    return fused && nvec == 0 ? M->view_of(ws.z) : AsmView{ws.z, 0};
+  }
+  AsmView Ap_view() const { return fused ? A->view_of(ws.Ap) : AsmView{ws.Ap, 0}; }
+  // Lanczos bookkeeping of the eigCG family for the iteration just enqueued
+  void eig_record() {
     const int pre = M != nullptr;
     double *tv = eig.has_tvec ? ws.etvec.p : nullptr;
-    hipLaunchKernelGGL(k_eig_vec, dim3(g), dim3(NT), 0, s, n, ws.st, ws.ees.p, pre, eig.spdim, zz, ws.Ap, ws.eV.p, tv);
+    hipLaunchKernelGGL(k_eig_vec, dim3(g), dim3(NT), 0, s, n, ws.st, ws.ees.p, pre, eig.spdim, z_view(), Ap_view(), ws.eV.p, tv);
     if (eig.has_tvec)
       hipLaunchKernelGGL(k_eig_coupling, dim3(g, 2 * ws.e_nvec), dim3(NT), 0, s, n, ws.st, ws.ees.p, ws.eV.p, ws.etvec.p,
                          ws.epart.p);
@@ -243,6 +250,7 @@ struct Krylov {
 #define MI_CALL(E) hipLaunchKernelGGL((k_fused_cg<E>), dim3(1), dim3(NTF), 0, s, n, ws.st, vAp, ws.p, ws.x, ws.r, ws.res_norm.p)
         MI_EPT_DISPATCH(MI_CALL);
 #undef MI_CALL
+        if (eig.tag) eig_record();
         MI_HIP(hipGetLastError());
         return;
       }
@@ -268,6 +276,7 @@ struct Krylov {
 #define MI_CALL(E) hipLaunchKernelGGL((k_fused_p<E>), dim3(1), dim3(NTF), 0, s, n, ws.st, vz, ws.r, ws.p, Wp, mup, nvec, ws.res_norm.p, pre, lup, pivp, ws.part_mu.p)
       MI_EPT_DISPATCH(MI_CALL);                                       // beta; [mu;] p; it += 1; res_norm[it]; stop rule
 #undef MI_CALL
+      if (eig.tag) eig_record();
       MI_HIP(hipGetLastError());
       return;
     }
@@ -298,7 +307,7 @@ struct Krylov {
     if (nvec > 0) project(ws.AW.p, zz, dn);                           // mu .= WtAW \ (WtA * z)
     hipLaunchKernelGGL(k_update_p, dim3(g), dim3(NT), 0, s, n, ws.st, ws.part_rr, ws.part_rz, g, zz, ws.p, Wp, mup, nvec,
                        ws.res_norm.p, pre);                           // beta; p; it += 1; res_norm[it]; stop rule
-    if (eig.tag) eig_record(zz);
+    if (eig.tag) eig_record();
     MI_HIP(hipGetLastError());
   }
 

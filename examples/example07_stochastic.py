@@ -8,6 +8,11 @@ S_d and NN_t on the host (as the reference does), then on the GPU
     defpcg(S, b_schur, 0, W_0, ΠSnn_0)                  deflation with the nev least-dominant eigenvectors of
                                                         S_0 (the `defpcg` variant that Example07 keeps in its
                                                         trailing comment block, with W fixed instead of recycled)
+    eigpcg / eigdefpcg(S, b_schur, 0, ΠSnn_0, W, spdim)   (--recycle) BASELINE config 5's "deflated Schur-PCG with
+                                                        recycled W": the first system runs eigpcg, every later one
+                                                        eigdefpcg with the W the previous solve returned
+                                                        (Example09_..._Functions.jl:345, 364; nvec = 1.25 ndom,
+                                                        spdim = 3 ndom), the chain being per rank
 and record the iteration counts. Realizations are independent: under torch.distributed.run each rank takes
 realizations rank, rank+world, ... on its own GPU (replicas only, no collective in the solve).
 
@@ -37,6 +42,7 @@ def main():
     ap.add_argument("--seed", type=int, default=481456)
     ap.add_argument("--out", default="")
     ap.add_argument("--device-assembly", action="store_true")
+    ap.add_argument("--recycle", action="store_true")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     pkg = graft.load_package()
@@ -61,7 +67,8 @@ def main():
     if args.device_assembly:
         plan = fem.make_assembly_plan(mesh.cells, mesh.points, P0.epart, sub, f, uexact)
         dev_plan = api.AssemblyPlan(ctx, plan)
-    iters_0, iters_t, iters_def = [], [], []
+    iters_0, iters_t, iters_def, iters_rec = [], [], [], []
+    W_rec, nvec, spdim = None, int(1.25 * ndom), 3 * ndom
     for ireal in range(rank, args.nreals, world):
         blocks = plan.blocks(dev_plan.run(np.exp(gs[ireal]))) if plan else None                       # :162-171 on the GPU
         P = fem.build_schur_problem(args.N, args.px, args.py, np.exp(gs[ireal]), f, uexact, mesh=mesh,
@@ -72,10 +79,22 @@ def main():
         iters_0.append(api.pcg(S, P.b_schur, x0, ΠSnn_0)[1])                                          # :273
         iters_t.append(api.pcg(S, P.b_schur, x0, ΠSnn_t)[1])                                          # :277
         iters_def.append(api.defpcg(S, P.b_schur, x0, W_0, ΠSnn_0)[1])
+        rec = ""
+        if args.recycle:
+            try:
+                if W_rec is None:
+                    _, it, _, W_rec = api.eigpcg(S, P.b_schur, x0, ΠSnn_0, nvec, spdim)
+                else:
+                    _, it, _, W_rec = api.eigdefpcg(S, P.b_schur, x0, ΠSnn_0, W_rec, spdim)
+                iters_rec.append(it)
+                rec = f"  eig(def)pcg(W recycled, NN_0) it={it}"
+            except (api.BoundsError, api.SingularException) as e:          # Example09:355-375: status = -1
+                rec = f"  recycling stopped: {type(e).__name__}"
+                W_rec = None
         print(f"[rank {rank}] realization {ireal}: pcg(NN_0) it={iters_0[-1]}  pcg(NN_t) it={iters_t[-1]}  "
-              f"defpcg(W_0, NN_0) it={iters_def[-1]}", flush=True)
+              f"defpcg(W_0, NN_0) it={iters_def[-1]}{rec}", flush=True)
     if args.out:                                                                                       # :281-285 npz of iteration counts
-        np.savez(args.out.format(rank=rank), iters_0=iters_0, iters_t=iters_t, iters_def=iters_def)
+        np.savez(args.out.format(rank=rank), iters_0=iters_0, iters_t=iters_t, iters_def=iters_def, iters_rec=iters_rec)
     print(f"[rank {rank}] mean its: NN_0 {np.mean(iters_0):.1f}  NN_t {np.mean(iters_t):.1f}  def {np.mean(iters_def):.1f}")
 
 

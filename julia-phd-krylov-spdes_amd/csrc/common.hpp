@@ -129,6 +129,26 @@ struct SolverWorkspace;
 }  // namespace mi
 
 // ------------------------------------------------------------------ the context
+namespace mi {
+// Pinned (device-visible) host buffer: kernels read / write it directly over PCIe, so a host-pointer call needs no
+// separate copy operations on the stream.
+struct PinnedBuf {
+  double *p = nullptr;
+  size_t n = 0;
+  void ensure(size_t m) {
+    if (m <= n) return;
+    release();
+    MI_HIP(hipHostMalloc((void **)&p, (m ? m : 1) * sizeof(double)));
+    n = m;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr; n = 0;
+  }
+  ~PinnedBuf() { release(); }
+};
+}  // namespace mi
+
 struct mi_ctx_s {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -140,6 +160,7 @@ struct mi_ctx_s {
   bool no_graph = false;  // set when a captured collective could not be instantiated: eager launches from then on
   // scratch for BLAS-1 entry points and reductions
   mi::DevBuf<double> scratch_a, scratch_b, partials, scalar;
+  mi::PinnedBuf pin_b, pin_x;  // host-pointer solves: b, x0 in / x out without stream copies
   // solver workspaces keyed by problem size; graphs keyed inside
   std::map<int64_t, std::unique_ptr<mi::SolverWorkspace>> workspaces;
   void use() const { MI_HIP(hipSetDevice(device)); }

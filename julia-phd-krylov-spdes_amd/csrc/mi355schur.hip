@@ -81,13 +81,17 @@ static int run_solver(mi_op_t A, mi_op_t M, const double *b, double *x, const do
   return guarded([&]() -> int {
     c->use();
     const size_t n = (size_t)a->n;
-    In bi(c, b, n, c->scratch_a);
-    InOut xi(c, x, n, c->scratch_b, true);
     DevBuf<double> wstage;
     In wi(c, W, want_W ? n * (size_t)nvec : 0, wstage);
     Krylov k(c, a, m, want_W ? (int)nvec : 0);
-    const int rc = k.solve(bi.dev, xi.dev, wi.dev, maxit, eps, res_norm, res_cap, it);
-    xi.finish();
+    if (c->ptr_mode == MI_PTR_DEVICE) return k.solve(b, x, wi.dev, maxit, eps, res_norm, res_cap, it);
+    // Host pointers (Julia arrays): b and x0 go through pinned buffers that the solve's entry kernel reads and its
+    // exit kernel writes directly — no copy operations on the stream, one wait per solve.
+    c->pin_b.ensure(n); c->pin_x.ensure(n);
+    std::memcpy(c->pin_b.p, b, n * sizeof(double));
+    std::memcpy(c->pin_x.p, x, n * sizeof(double));
+    const int rc = k.solve(c->pin_b.p, c->pin_x.p, wi.dev, maxit, eps, res_norm, res_cap, it);  // synchronises before returning
+    std::memcpy(x, c->pin_x.p, n * sizeof(double));
     return rc;
   });
 }

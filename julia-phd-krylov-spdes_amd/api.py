@@ -425,6 +425,17 @@ class MatrixFreeLocalSchurs(Operator):
         return out
 
 
+class LocalSchur(MatrixFreeLocalSchurs):
+    """`xd -> apply_local_schur(A_IIdd, A_IΓdd, A_ΓΓdd, xd; precond, reltol)` (EPDD.jl:639-654): ONE subdomain, vectors in
+    its own Γ_d numbering — S_d xd = A_ΓΓdd xd - A_IΓdd' (A_IIdd \ (A_IΓdd xd)). What `assemble_local_schurs` applies to the
+    unit vectors (EPDD.jl:667-695) and `prepare_neumann_neumann_schur_precond` wraps (:1152-1189)."""
+
+    def __init__(self, ctx: Context, A_IIdd, A_IΓdd, A_ΓΓdd, interior_solver=None, reltol: float = 1e-9):
+        n = A_ΓΓdd.shape[0]
+        super().__init__(ctx, [A_IIdd], [A_IΓdd], [A_ΓΓdd], [np.arange(n, dtype=np.int64)], np.ones(n, dtype=np.int64),
+                         None if interior_solver is None else [interior_solver], reltol)
+
+
 class AssemblyPlan:
     """Device executor of a `fem.AssemblyPlan` (`mi_plan_t`): `run(a)` is the numeric half of
     `prepare_local_schurs(cells, points, epart, ..., a, f, uexact)` (EPDD.jl:389-546) for a new coefficient vector."""
@@ -496,6 +507,10 @@ class GlobalSchur(Operator):
 
 
 # reference-named free functions
+def apply_local_schur(S_d: LocalSchur, xd):
+    return S_d.apply(xd)
+
+
 def apply_local_schurs(S: Operator, x):
     return S.apply(x)
 

@@ -504,3 +504,18 @@ def test_initial_guess_zero_shortcut_and_nonzero_guesses(pkg, ctx, orc, ragged):
         got = api.pcg(S, bt, xt, M)
         want = orc.pcg(So, b, x0.copy(), Mo)
         assert got[1] == want[1] and np.isclose(got[2][0], want[2][0], rtol=1e-12)
+
+
+def test_apply_local_schur_single_subdomain(pkg, ctx, ragged):
+    """a7 (EPDD.jl:639-654): one subdomain in its own Γ_d numbering, against the assembled S_d of the same subdomain
+    (host callback: sparse-direct interior solve; device: interior CG to reltol 1e-11)."""
+    api = pkg.api
+    P = ragged
+    rng = np.random.default_rng(21)
+    for d in (0, P.sub.ndom - 1):
+        xd = rng.standard_normal(P.sub.n_Γd[d])
+        want = P.Sd[d] @ xd
+        for solver, tol in ((P.solvers[d], 1e-10), (None, 1e-7)):
+            S_d = api.LocalSchur(ctx, P.A_IIdd[d], P.A_IΓdd[d], P.A_ΓΓdd[d], solver, reltol=1e-11)
+            got = api.apply_local_schur(S_d, xd)
+            assert np.linalg.norm(got - want) <= tol * np.linalg.norm(want)

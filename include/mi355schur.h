@@ -217,6 +217,9 @@ int mi_assembly_run(mi_plan_t plan, const double *a_nodal, double *values);
 int mi_assembly_plan_destroy(mi_plan_t plan);
 int mi_schur_matfree_set_values(mi_op_t op, const double *ii_val, const double *ig_val, const double *gg_val);
 int mi_schur_matfree_rhs(mi_op_t op, const double *b_I, const double *b_gamma, double *b_schur);
+/* `get_subdomain_solutions(u_Γ, A_IId, A_IΓd, b_Id)` (EPDD.jl:1014-1025): u_Id = A_IIdd \ (b_Id - A_IΓdd u_Γd) for the
+ * operator's subdomains with its own interior solve; b_I and u_I are concatenations over those subdomains. */
+int mi_schur_matfree_interior_solutions(mi_op_t op, const double *u_gamma, const double *b_I, double *u_I);
 
 /* ---------------------------------------------------------------- eigCG family and Init-CG (recycling solvers)
  * Reference signatures (RecyclingKrylovSolvers/eigcg.jl:27-33, 143-150; defcg.jl:111-116, 337-343; initcg.jl:28-33,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "mi_assembly_plan_destroy": [vp],
     "mi_schur_matfree_set_values": [vp, vp, vp, vp],
     "mi_schur_matfree_rhs": [vp, vp, vp, vp],
+    "mi_schur_matfree_interior_solutions": [vp, vp, vp, vp],
     "mi_eigcg": [vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],
     "mi_eigpcg": [vp, vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],
     "mi_eigdefcg": [vp, vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],

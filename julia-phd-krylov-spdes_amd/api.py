@@ -425,6 +425,26 @@ class MatrixFreeLocalSchurs(Operator):
         return out
 
 
+def _interior_solutions(self, u_Γ, b_I):
+    """`get_subdomain_solutions(u_Γ, A_IId, A_IΓd, b_Id)` (EPDD.jl:1014-1025) with this operator's interior solve:
+    the concatenation of u_Id = A_IIdd \\ (b_Id - A_IΓdd u_Γd) over this operator's subdomains."""
+    self.ctx._mode_for(u_Γ, b_I)
+    k1, p1 = self.ctx._ptr(u_Γ, self.n)
+    k2, p2 = self.ctx._ptr(b_I)
+    if _is_torch(b_I):
+        import torch
+        out = torch.empty_like(b_I)
+        po = vp(out.data_ptr())
+    else:
+        out = np.empty(np.asarray(b_I).size)
+        po = vp(out.ctypes.data)
+    check(self.ctx._L.mi_schur_matfree_interior_solutions(self._h, p1, p2, po))
+    return out
+
+
+MatrixFreeLocalSchurs.interior_solutions = _interior_solutions
+
+
 class LocalSchur(MatrixFreeLocalSchurs):
     """`xd -> apply_local_schur(A_IIdd, A_IΓdd, A_ΓΓdd, xd; precond, reltol)` (EPDD.jl:639-654): ONE subdomain, vectors in
     its own Γ_d numbering — S_d xd = A_ΓΓdd xd - A_IΓdd' (A_IIdd \ (A_IΓdd xd)). What `assemble_local_schurs` applies to the

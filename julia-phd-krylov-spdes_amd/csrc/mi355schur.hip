@@ -664,6 +664,23 @@ int mi_schur_matfree_rhs(mi_op_t op, const double *b_I, const double *b_gamma, d
   });
 }
 
+int mi_schur_matfree_interior_solutions(mi_op_t op, const double *u_gamma, const double *b_I, double *u_I) {
+  MatfreeSchurOp *m = as_matfree(op);
+  if (!m || !u_gamma || (m->ni_tot && (!b_I || !u_I)))
+    return fail(MI_ERR_BAD_ARG, "mi_schur_matfree_interior_solutions: not a matrix-free local-Schur operator, or NULL argument");
+  mi_ctx_s *c = m->ctx;
+  return guarded([&]() -> int {
+    c->use();
+    DevBuf<double> s1, s2;
+    In ug(c, u_gamma, (size_t)m->n, c->scratch_a), bi(c, b_I, (size_t)m->ni_tot, s1);
+    InOut out(c, u_I, (size_t)m->ni_tot, s2, false);
+    m->interior_solutions(ug.dev, bi.dev, out.dev);
+    out.finish();
+    MI_HIP(hipStreamSynchronize(c->stream));
+    return MI_OK;
+  });
+}
+
 // ---------------------------------------------------------------- events
 int mi_event_create(mi_event_t *ev) {
   if (!ev) return fail(MI_ERR_BAD_ARG, "ev is NULL");

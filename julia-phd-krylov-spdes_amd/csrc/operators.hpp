@@ -655,6 +655,25 @@ struct MatfreeSchurOp : Operator {
     hipLaunchKernelGGL(k_sub, dim3(vec_grid(n)), dim3(NT), 0, s, (int)n, b_gamma, t2.p, out);
     MI_HIP(hipGetLastError());
   }
+  // u_Id = A_IIdd^{-1} (b_Id - A_IΓdd u_Γd) for every local subdomain (get_subdomain_solutions, EPDD.jl:1014-1025);
+  // b_I / u_I: concatenated over the local subdomains
+  void interior_solutions(const double *u_gamma, const double *b_I, double *u_I) {
+    hipStream_t s = ctx->stream;
+    if (!maps.nloc) return;
+    hipLaunchKernelGGL(k_gather, dim3(vec_grid(maps.nloc)), dim3(NT), 0, s, maps.nloc, maps.gidx.p, u_gamma, xcat.p);
+    MI_HIP(hipGetLastError());
+    A_IG.launch(1, xcat.p, b_I, rhs.p, nullptr, s);  // rhs = b_I - A_IΓ u_Γd
+    if (icg) {
+      icg->solve(rhs.p, u_I);
+    } else {
+      MI_HIP(hipMemcpyAsync(stage.rhs, rhs.p, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+      for (int dl = 0; dl < maps.ndl; ++dl)
+        if (solve(user, d0 + dl, ni[dl], stage.rhs + ioff[dl], stage.sol + ioff[dl]) != 0)
+          raise(MI_ERR_CALLBACK, "interior solve callback failed on subdomain %lld", (long long)(d0 + dl));
+      MI_HIP(hipMemcpyAsync(u_I, stage.sol, sizeof(double) * ni_tot, hipMemcpyHostToDevice, s));
+    }
+  }
   void bytes(int64_t *a, int64_t *d) const override {
     *a = A_IG.bytes() + A_GI.bytes() + A_GG.bytes() + 16ll * ni_tot;
     *d = icg ? icg->A.bytes() : A_IG.bytes();

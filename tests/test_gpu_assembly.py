@@ -65,6 +65,10 @@ def test_realization_update_on_the_device(pkg, ctx, orc, fem):
     assert np.array_equal(S * x, S_fresh * x)                          # same values, same kernels: same bits
     b_dev = S.schur_rhs(bI, bΓ).cpu().numpy()
     assert np.linalg.norm(b_dev - P1.b_schur) <= 1e-8 * np.linalg.norm(P1.b_schur)
+    # back-substitution on the device (get_subdomain_solutions, EPDD.jl:1014-1025) against sparse-direct interior solves
+    u_I = S.interior_solutions(torch.from_numpy(x).cuda(), bI).cpu().numpy()
+    ref = np.concatenate([P1.solvers[d](P1.b_Id[d] - P1.A_IΓdd[d] @ x[gi[d]]) for d in range(sub.ndom)])
+    assert np.linalg.norm(u_I - ref) <= 1e-8 * np.linalg.norm(ref)
     # the update of one block only: others keep their values
     S.set_values(None, None, gg)
     assert np.array_equal(S * x, S_fresh * x)

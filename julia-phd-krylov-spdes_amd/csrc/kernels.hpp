@@ -79,7 +79,13 @@ __device__ __forceinline__ void block_sum2_t(double &a, double &b, double *sm) {
 // Sum of `g` per-workgroup partials, in a fixed order, identical in every workgroup.
 __device__ __forceinline__ double sum_partials(const double *part, int g, double *sm) {
   double v = 0.0;
-  for (int i = threadIdx.x; i < g; i += NT) v += part[i];
+  for (int i0 = threadIdx.x; i0 < g; i0 += 8 * NT) {  // eight loads in flight per thread (a plain loop pays one round trip each)
+    double t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = i0 + k * NT < g ? part[i0 + k * NT] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += t[k];
+  }
   return block_sum(v, sm);
 }
 
@@ -110,7 +116,19 @@ __global__ __launch_bounds__(NT) void k_dot_partial(int n, const double *__restr
   if (done && *done) return;
   __shared__ double sm[NT / 64 + 1];
   double s = 0.0;
-  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) s += x[i] * y[i];
+  const int stride = gridDim.x * NT;
+  for (int i0 = blockIdx.x * NT + threadIdx.x; i0 < n; i0 += 4 * stride) {  // four elements in flight per thread, summed in order
+    double a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * stride;
+      a[k] = i < n ? x[i] : 0.0;
+      b[k] = i < n ? y[i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i0 + k * stride < n) s += a[k] * b[k];
+  }
   s = block_sum(s, sm);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
@@ -247,7 +265,13 @@ struct IcgMeta {
 };
 __device__ __forceinline__ double icg_dom_sum(const double *part, int b0, int b1, double *sm) {
   double v = 0.0;
-  for (int i = b0 + (int)threadIdx.x; i < b1; i += NT) v += part[i];
+  for (int i0 = b0 + (int)threadIdx.x; i0 < b1; i0 += 8 * NT) {  // eight loads in flight per thread, added in order
+    double t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = i0 + k * NT < b1 ? part[i0 + k * NT] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += t[k];
+  }
   return block_sum(v, sm);
 }
 // r = rhs; x = 0; u = r (beta*0); partial r'r
@@ -899,16 +923,30 @@ __global__ __launch_bounds__(NT) void k_update_xr(int n, SolverState *st, const 
   const double num = precond ? st->rTz : st->rTr;
   const double alpha = num / d;
   double srr = 0.0, srz = 0.0;
-  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
-    const double pi = p[i];
-    x[i] = x[i] + alpha * pi;          // axpy!(alpha, p, x)
-    const double ri = r[i] + (-alpha) * Ap[i];  // axpy!(-alpha, Ap, r)
-    r[i] = ri;
-    srr += ri * ri;
-    if (diag) {
-      const double zi = diag == 2 ? dinv[i] * ri : ri;
-      z[i] = zi;
-      srz += ri * zi;
+  const int stride = gridDim.x * NT;
+  for (int i0 = blockIdx.x * NT + threadIdx.x; i0 < n; i0 += 4 * stride) {  // the loads of four elements go out together
+    double pv[4], xv[4], rv[4], av[4], dv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * stride;
+      const bool ok = i < n;
+      pv[k] = ok ? p[i] : 0.0; xv[k] = ok ? x[i] : 0.0; rv[k] = ok ? r[i] : 0.0; av[k] = ok ? Ap[i] : 0.0;
+      dv[k] = ok && diag == 2 ? dinv[i] : 1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * stride;
+      if (i < n) {
+        x[i] = xv[k] + alpha * pv[k];              // axpy!(alpha, p, x)
+        const double ri = rv[k] + (-alpha) * av[k];  // axpy!(-alpha, Ap, r)
+        r[i] = ri;
+        srr += ri * ri;
+        if (diag) {
+          const double zi = diag == 2 ? dv[k] * ri : ri;
+          z[i] = zi;
+          srz += ri * zi;
+        }
+      }
     }
   }
   srr = block_sum(srr, sm);
@@ -939,12 +977,24 @@ __global__ __launch_bounds__(NT) void k_update_p(int n, SolverState *st, const d
   const double old = precond ? st->rTz_prev : st->rTr_prev;
   double beta = 1. / old;
   beta *= rz;
-  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
-    double v = beta * p[i] + z[i];     // axpby!(1, z, beta, p)
-    if (nvec > 0) {
-      v = v - w_times_mu(W, n, i, mu, nvec);   // (W*mu)[i], column-axpy order
+  const int stride = gridDim.x * NT;
+  for (int i0 = blockIdx.x * NT + threadIdx.x; i0 < n; i0 += 4 * stride) {  // four elements in flight per thread
+    double pv[4], zv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * stride;
+      pv[k] = i < n ? p[i] : 0.0;
+      zv[k] = i < n ? z[i] : 0.0;
     }
-    p[i] = v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * stride;
+      if (i < n) {
+        double v = beta * pv[k] + zv[k];     // axpby!(1, z, beta, p)
+        if (nvec > 0) v = v - w_times_mu(W, n, i, mu, nvec);   // (W*mu)[i], column-axpy order
+        p[i] = v;
+      }
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->rTr = rr; st->rTz = rz; st->beta = beta;

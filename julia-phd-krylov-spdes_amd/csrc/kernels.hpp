@@ -190,8 +190,9 @@ __global__ __launch_bounds__(NT) void k_spmv_csr(int nblocks, const SpmvBlock *_
     // row bounds of this thread's first two rows: independent of phase 1, so issue the loads now
     const int ra = r0 + threadIdx.x, rbb = ra + NT;
     int a0 = 0, e0 = 0, a1 = 0, e1 = 0;
-    if (ra < r1) { a0 = rowptr[ra] - k0; e0 = rowptr[ra + 1] - k0; }
-    if (rbb < r1) { a1 = rowptr[rbb] - k0; e1 = rowptr[rbb + 1] - k0; }
+    double w0 = 0.0, w1 = 0.0;  // the dot's weights for those rows too: one fewer round trip in the epilogue
+    if (ra < r1) { a0 = rowptr[ra] - k0; e0 = rowptr[ra + 1] - k0; if (DOT) w0 = w[ra]; }
+    if (rbb < r1) { a1 = rowptr[rbb] - k0; e1 = rowptr[rbb + 1] - k0; if (DOT) w1 = w[rbb]; }
     if ((k0 & 1) == 0) {  // 16-byte aligned values, 8-byte aligned indices: two non-zeros per load
       const int npair = (nnz + 1) >> 1;
       for (int q = threadIdx.x; q < npair; q += NT) {
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(NT) void k_spmv_csr(int nblocks, const SpmvBlock *_
       for (int k = a; k < e; ++k) sum += prod[k];
       const double yr = MODE ? yin[r] - sum : sum;
       y[r] = yr;
-      if (DOT) wy += w[r] * yr;
+      if (DOT) wy += (i == 0 ? w0 : i == 1 ? w1 : w[r]) * yr;
     }
   } else {
     // a single row longer than the tile (never the case for P1-FEM blocks): tile by tile,
@@ -919,20 +920,26 @@ __global__ __launch_bounds__(NT) void k_update_xr(int n, SolverState *st, const 
                                                   double *__restrict__ part_rz) {
   if (st->done) return;
   __shared__ double sm[NT / 64 + 1];
-  const double d = sum_partials(part_pAp, g_in, sm);
-  const double num = precond ? st->rTz : st->rTr;
-  const double alpha = num / d;
-  double srr = 0.0, srz = 0.0;
+  // The element loads do not depend on alpha: the first four elements of every thread (all of them unless the grid is
+  // capped) are requested BEFORE the partial sums are reduced, so the kernel pays one memory round trip, not two.
   const int stride = gridDim.x * NT;
-  for (int i0 = blockIdx.x * NT + threadIdx.x; i0 < n; i0 += 4 * stride) {  // the loads of four elements go out together
-    double pv[4], xv[4], rv[4], av[4], dv[4];
+  int i0 = blockIdx.x * NT + threadIdx.x;
+  double pv[4], xv[4], rv[4], av[4], dv[4];
+  auto load = [&](int base) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int i = i0 + k * stride;
+      const int i = base + k * stride;
       const bool ok = i < n;
       pv[k] = ok ? p[i] : 0.0; xv[k] = ok ? x[i] : 0.0; rv[k] = ok ? r[i] : 0.0; av[k] = ok ? Ap[i] : 0.0;
       dv[k] = ok && diag == 2 ? dinv[i] : 1.0;
     }
+  };
+  load(i0);
+  const double d = sum_partials(part_pAp, g_in, sm);
+  const double num = precond ? st->rTz : st->rTr;
+  const double alpha = num / d;
+  double srr = 0.0, srz = 0.0;
+  for (;;) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = i0 + k * stride;
@@ -948,6 +955,9 @@ __global__ __launch_bounds__(NT) void k_update_xr(int n, SolverState *st, const 
         }
       }
     }
+    i0 += 4 * stride;
+    if (i0 >= n) break;
+    load(i0);
   }
   srr = block_sum(srr, sm);
   if (diag) srz = block_sum(srz, sm);
@@ -972,20 +982,24 @@ __global__ __launch_bounds__(NT) void k_update_p(int n, SolverState *st, const d
   if (threadIdx.x == 0) was_done = st->done;
   __syncthreads();
   if (was_done) return;
+  const int stride = gridDim.x * NT;
+  int i0 = blockIdx.x * NT + threadIdx.x;
+  double pv[4], zv[4];
+  auto load = [&](int base) {  // independent of beta: requested before the reductions (see k_update_xr)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base + k * stride;
+      pv[k] = i < n ? p[i] : 0.0;
+      zv[k] = i < n ? z[i] : 0.0;
+    }
+  };
+  load(i0);
   const double rr = sum_partials(part_rr, g_in, sm);
   const double rz = precond ? sum_partials(part_rz, g_in, sm) : rr;
   const double old = precond ? st->rTz_prev : st->rTr_prev;
   double beta = 1. / old;
   beta *= rz;
-  const int stride = gridDim.x * NT;
-  for (int i0 = blockIdx.x * NT + threadIdx.x; i0 < n; i0 += 4 * stride) {  // four elements in flight per thread
-    double pv[4], zv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = i0 + k * stride;
-      pv[k] = i < n ? p[i] : 0.0;
-      zv[k] = i < n ? z[i] : 0.0;
-    }
+  for (;;) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = i0 + k * stride;
@@ -995,6 +1009,9 @@ __global__ __launch_bounds__(NT) void k_update_p(int n, SolverState *st, const d
         p[i] = v;
       }
     }
+    i0 += 4 * stride;
+    if (i0 >= n) break;
+    load(i0);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->rTr = rr; st->rTz = rz; st->beta = beta;

@@ -27,7 +27,7 @@ constexpr int64_t RES_STAGE = 8192;
 struct GraphKey {
   const Operator *A, *M;
   int nvec, chunk;  // chunk > 0: that many iterations; chunk < 0: set-up + (-chunk) iterations
-  int tag = 0;      // 0: cg/pcg/defcg/defpcg; eigCG family: 1 + kind + 8*spdim (recording kernels ride on the iteration)
+  int tag = 0;      // 4*(0: cg/pcg/defcg/defpcg; eigCG family: 1 + kind + 8*spdim) + loop form (fused, folded)
   bool operator<(const GraphKey &o) const {
     return std::tie(A, M, nvec, chunk, tag) < std::tie(o.A, o.M, o.nvec, o.chunk, o.tag);
   }
@@ -360,7 +360,7 @@ struct Krylov {
 
   // chunk > 0: `chunk` iterations; chunk < 0: set-up tail + (-chunk) iterations.
   hipGraphExec_t graph(int chunk) {
-    GraphKey key{A, M, nvec, chunk, eig.tag};
+    GraphKey key{A, M, nvec, chunk, eig.tag * 4 + (fused ? 1 : 0) + (fold ? 2 : 0)};  // the loop form is part of the graph
     auto it = ws.graphs.find(key);
     if (it != ws.graphs.end()) return it->second;
     hipGraph_t gr = nullptr;

@@ -186,3 +186,42 @@ def test_eig_errors(pkg, ctx, toy):
     W = np.zeros((n, 3))
     with pytest.raises(api.SingularException):
         api.eigdefpcg(S, toy.b_schur, np.zeros(n), M, W, 9)         # WtAW singular, as in defpcg
+
+
+def test_eig_multi_workgroup_loop_matches_fused(pkg, ctx, orc, toy, monkeypatch):
+    """Large systems (n > 8192) run the eigCG family on the multi-workgroup loop kernels; force that path on the toy
+    system and compare with the fused-loop result and the oracle."""
+    S, M = gpu_ops(pkg, ctx, toy)
+    So, Mo = orc_ops(orc, toy)
+    n = toy.sub.n_Γ
+    api = pkg.api
+    fused = api.eigpcg(S, toy.b_schur, np.zeros(n), M, 3, 8)
+    fused_cg = api.eigcg(S, toy.b_schur, np.zeros(n), 5, 14)
+    monkeypatch.setenv("MI355_NO_FUSED", "1")
+    got = api.eigpcg(S, toy.b_schur, np.zeros(n), M, 3, 8)
+    got_cg = api.eigcg(S, toy.b_schur, np.zeros(n), 5, 14)
+    monkeypatch.delenv("MI355_NO_FUSED")
+    assert_history(got[:3], orc.eigpcg(So, toy.b_schur, np.zeros(n), Mo, 3, 8)[:3])
+    assert got[1] == fused[1] and np.allclose(got[2], fused[2], rtol=1e-8, atol=1e-12 * fused[2][0])
+    assert_space(So, got[3], fused[3])
+    assert_history(got_cg[:3], fused_cg[:3], apply=So, b=toy.b_schur)
+    assert_space(So, got_cg[3], fused_cg[3])
+
+
+def test_eigpcg_large_system_multi_workgroup(pkg, ctx, orc, fem):
+    """n = 9 604 > 8 192: the genuinely multi-workgroup path (CSR SpMV with the dot in its epilogue, Jacobi folded into the
+    r-update, recording kernels over several workgroups). A long Jacobi-PCG run: history to the long-run bar, the recycled
+    space to 1e-3 (its vectors are late CG iterates, which drift between summation orders — see assert_history)."""
+    mesh = fem.get_mesh(100)
+    d = fem.get_dirichlet_inds(mesh.points, mesh.point_marker)
+    A, b = fem.do_isotropic_elliptic_assembly(mesh.cells, mesh.points, d, mesh.point_marker, a_example01, f_m1, u3)
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    assert n > 8192
+    api = pkg.api
+    Ao, Mo = orc.csc_operator(A), orc.jacobi_operator(A.diagonal())
+    want = orc.eigpcg(Ao, b, np.zeros(n), Mo, 6, 20)
+    got = api.eigpcg(api.SparseMatrixCSC(ctx, A), b, np.zeros(n), api.JacobiPreconditioner(ctx, A.diagonal()), 6, 20)
+    assert_history(got[:3], want[:3], apply=Ao, b=b)
+    assert np.all(np.isfinite(got[3])) and sin_theta(got[3], want[3]) <= 1e-3
+    assert np.allclose(ritz_values(Ao, got[3]), ritz_values(Ao, want[3]), rtol=1e-3)

@@ -32,11 +32,17 @@ def main():
     for k in sorted(f):
         if "mi::" not in k:
             continue
-        fv = sorted(v for v in f[k])
-        wv = sorted(v for v in w.get(k, [0.0]))
-        # launches that return at once (stop flag) fetch ~nothing: take the upper half's median
-        fm = fv[len(fv) * 3 // 4] if fv else 0.0
-        wm = wv[len(wv) * 3 // 4] if wv else 0.0
+        # launches that return at once (stop flag, x0 == 0 shortcut) fetch ~nothing: median over the dispatches that
+        # move at least half of what the largest one moves
+        def working_median(vals):
+            vals = sorted(vals)
+            if not vals:
+                return 0.0
+            work = [v for v in vals if v >= 0.5 * vals[-1]]
+            return work[len(work) // 2]
+        fm = working_median(f[k])
+        wm = working_median(w.get(k, [0.0]))
+        fv = f[k]
         res[k] = {"dispatches": len(fv), "fetch_KiB_raw": fm, "write_KiB_raw": wm,
                   "bytes_per_launch": int((2.0 * fm + wm) * 1024)}
     # dominant kernel of the timed region = the folded PCG GEMV launches (both phases); else the plain S-apply GEMV

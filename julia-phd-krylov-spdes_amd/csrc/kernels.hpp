@@ -710,15 +710,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     if (j < n && ri >= 0 && ri < NR) {
       const int loc = off + j;
       o_q = q;
+      // everything an owner needs is requested unconditionally (a load behind `if (owner)` would wait for jrank first:
+      // a second memory round trip on the way to the operand barrier); x[g] — a dependent load — is consumed only in the
+      // epilogue, after the matrix stream
       o_own = f.jrank[loc] == 0;
-      if (o_own) {
-        if (PHASE == 1) { o_a = first1 ? 0.0 : f.p_nxt[loc]; o_g = m.gidx[loc]; o_x = f.x[o_g]; }
-        else o_a = f.r_nxt[loc];
+      if (PHASE == 1) { o_a = first1 ? 0.0 : f.p_nxt[loc]; o_g = m.gidx[loc]; }
+      else o_a = f.r_nxt[loc];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (k < W) o_peer[k] = f.peer[loc * W + k];
-      }
+      for (int k = 0; k < 4; ++k) if (k < W) o_peer[k] = f.peer[loc * W + k];
     }
   }
+  if (PHASE == 1 && o_q >= 0 && o_own) o_x = f.x[o_g];
   // lane 0 of every wave stores the results of its RPW rows into the contribution rows of all sharing subdomains
   int e_tgt[RPW][4];
   double e_cnt[RPW];
@@ -785,7 +787,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
         rowv[ri] = v;
         if (o_own) {                                      // owner of this Γ node
           if (PHASE == 1) {
-            f.x[o_g] = o_x + coef * o_a;                  // x + alpha*p
             rowc0[ri] = v * v;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -824,6 +825,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
       rowc1[ri] = (r < n ? rowv[ri] : 0.0) * y;    // r_g * z-contribution  /  p_g * Ap-contribution
     }
   }
+  if (PHASE == 1 && o_q >= 0 && o_own) f.x[o_g] = o_x + coef * o_a;  // x + alpha*p (cg.jl:97), off the critical path
   __syncthreads();
   if (threadIdx.x < 64) {  // per-tile partials of the next dot products: one shuffle tree over the NR row terms
     double a = 0.0, b = 0.0;

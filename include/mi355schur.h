@@ -80,6 +80,14 @@ int mi_ctx_set_chunk(mi_ctx_t ctx, int iterations_per_graph);
 int mi_comm_unique_id(void *id_out);
 int mi_ctx_comm_init(mi_ctx_t ctx, const void *id, int rank, int n_ranks);
 int mi_ctx_comm_destroy(mi_ctx_t ctx);
+/* Test facility: an in-process stand-in for the communicator. `n_ranks` contexts of ONE process (one host thread each,
+ * any devices, typically the same one) call mi_ctx_loopback_init with the same group and then behave like ranks of a
+ * multi-GPU job: operators built from a slice of the subdomains are sharded and their all-reduces sum the ranks'
+ * buffers through device memory with host-side rendezvous (eager launches, no graphs). RCCL refuses two ranks on
+ * one device; this is how the sharded paths are exercised on a single-GPU box (tests/test_gpu_parity.py). */
+int mi_loopback_group_create(int n_ranks, void **group);
+int mi_loopback_group_destroy(void *group);
+int mi_ctx_loopback_init(mi_ctx_t ctx, void *group, int rank);
 int mi_ctx_allreduce_sum(mi_ctx_t ctx, double *buf, int64_t n); /* in place, follows pointer mode */
 
 /* ---------------------------------------------------------------- operators
@@ -98,7 +106,9 @@ int mi_diag_create(mi_ctx_t ctx, int64_t n, const double *dinv, mi_op_t *op);
  * Sx = Σ_d R_d' S_d R_d x with dense local Schur complements.
  *   Sd[d]          n_gamma_d[d]^2 doubles, column-major (Julia `Array(Sd[d])`)
  *   gather_idx[d]  n_gamma_d[d] entries: Γ index of Γ_d slot l (the flattened Dict ind_Γd_Γ2l[d]:
- *                  gather_idx[d][lΓd] = lΓ)
+ *                  gather_idx[d][lΓd] = lΓ). Pass the lists of ALL subdomains on every rank, also outside
+ *                  [dom_begin, dom_end): they fix each subdomain's slot in the per-node contribution table, so that
+ *                  the ranks' tables are disjoint and their all-reduce reproduces the single-GPU Γ-sum bit for bit
  * The local slice [dom_begin, dom_end) of the ndom subdomains is applied by this rank. On a context with a
  * communicator a proper slice makes the operator SHARDED: its applies end with one RCCL all-reduce (of the table of
  * per-subdomain contributions, so the Γ-sum keeps the single-GPU order and bits). An operator created with

@@ -67,6 +67,9 @@ SIGNATURES = {
     "mi_pcg": [vp, vp, vp, vp, i64, C.c_double, f64p, i64, i64p],
     "mi_defcg": [vp, vp, vp, vp, i64, i64, C.c_double, f64p, i64, i64p],
     "mi_defpcg": [vp, vp, vp, vp, vp, i64, i64, C.c_double, f64p, i64, i64p],
+    "mi_loopback_group_create": [C.c_int, C.POINTER(vp)],
+    "mi_loopback_group_destroy": [vp],
+    "mi_ctx_loopback_init": [vp, vp, C.c_int],
     "mi_assembly_plan_create": [vp, i64, i64, i64p, C.c_int, f64p, f64p, f64p, f64p, i64, i64, i64p, i64p, C.POINTER(vp)],
     "mi_assembly_run": [vp, vp, vp],
     "mi_assembly_plan_destroy": [vp],

@@ -87,6 +87,12 @@ class Context:
             raise ValueError(f"expected {n} entries, got {a.size}")
         return a, vp(a.ctypes.data)
 
+    def loopback_init(self, group: "LoopbackGroup", rank: int) -> None:
+        """Make this context rank `rank` of an in-process group (one host thread per rank): the single-GPU stand-in for
+        `comm_init`, used to test the sharded operators (`mi_ctx_loopback_init`)."""
+        check(self._L.mi_ctx_loopback_init(self._h, group._h, C.c_int(rank)))
+        self.rank, self.n_ranks, self._group = rank, group.n, group
+
     def set_chunk(self, iterations_per_graph: int) -> None:
         check(self._L.mi_ctx_set_chunk(self._h, C.c_int(iterations_per_graph)))
 
@@ -160,6 +166,24 @@ class Context:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class LoopbackGroup:
+    """`mi_loopback_group_create`: n in-process "ranks" (test facility, see include/mi355schur.h)."""
+
+    def __init__(self, n: int):
+        L = _lib.load()
+        h = vp()
+        check(L.mi_loopback_group_create(C.c_int(n), C.byref(h)))
+        self._h, self._L, self.n = h, L, n
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.mi_loopback_group_destroy(self._h)
+                self._h = None
         except Exception:
             pass
 

@@ -7,7 +7,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -149,6 +151,30 @@ struct PinnedBuf {
 };
 }  // namespace mi
 
+namespace mi {
+// In-process stand-in for the RCCL communicator: N contexts ("ranks") of ONE process on one GPU, each driven by its own
+// host thread, sum their buffers through device memory with host-side rendezvous. It exists to exercise the sharded
+// (multi-GPU) code paths — slot-table union, non-local subdomains, replicated vectors — on a single-GPU box, where RCCL
+// refuses two ranks on the same device. Never captured into graphs (it synchronises with the host).
+struct LoopGroup {
+  int n;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  long long generation = 0;
+  std::vector<const double *> send;
+  std::vector<hipEvent_t> ready;
+  explicit LoopGroup(int n_) : n(n_), send(n_, nullptr), ready(n_, nullptr) {}
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const long long gen = generation;
+    if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
+    else cv.wait(lk, [&] { return generation != gen; });
+  }
+};
+void loop_allreduce(LoopGroup &g, int rank, const double *send, double *recv, size_t n, hipStream_t s);
+}  // namespace mi
+
 struct mi_ctx_s {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -156,7 +182,9 @@ struct mi_ctx_s {
   int ptr_mode = MI_PTR_HOST;
   int chunk = 8;
   ncclComm_t comm = nullptr;
+  mi::LoopGroup *loop = nullptr;  // in-process test communicator (see LoopGroup); mutually exclusive with comm
   int rank = 0, n_ranks = 1;
+  bool has_comm() const { return comm != nullptr || loop != nullptr; }
   bool no_graph = false;  // set when a captured collective could not be instantiated: eager launches from then on
   // scratch for BLAS-1 entry points and reductions
   mi::DevBuf<double> scratch_a, scratch_b, partials, scalar;
@@ -166,6 +194,7 @@ struct mi_ctx_s {
   void use() const { MI_HIP(hipSetDevice(device)); }
   void allreduce(double *buf, size_t n) { allreduce(buf, buf, n); }
   void allreduce(const double *send, double *recv, size_t n) {
+    if (loop) { mi::loop_allreduce(*loop, rank, send, recv, n, stream); return; }
     if (comm)  // also with n_ranks == 1, so that a single-GPU box exercises the captured collective
       MI_NCCL(mi::Rccl::get().AllReduce(send, recv, n, ncclDouble, ncclSum, comm, stream));
   }

@@ -158,7 +158,7 @@ struct EigKrylov {
     ws.ees.upload(&es0, 1, s);
     Snapshot h = fetch();
 
-    const bool use_graph = k.ctx->chunk > 0 && k.A->graph_safe() && (!k.M || k.M->graph_safe()) && !k.ctx->no_graph && !k.ctx->comm;
+    const bool use_graph = k.ctx->chunk > 0 && k.A->graph_safe() && (!k.M || k.M->graph_safe()) && !k.ctx->no_graph && !k.ctx->has_comm();
     for (int64_t guard = 0; guard < maxit + 4; ++guard) {
       if (h.es.restart_pending) {
         restart(h);

@@ -69,6 +69,34 @@ static double reduce_to_host(mi_ctx_s *c, int g, int take_sqrt) {
   return out;
 }
 
+// out[i] = Σ_r in[r][i], r ascending (the loopback communicator's reduction)
+__global__ __launch_bounds__(NT) void k_loop_sum(size_t n, int nr, const double *const *in, double *__restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+    double s = in[0][i];
+    for (int r = 1; r < nr; ++r) s += in[r][i];
+    out[i] = s;
+  }
+}
+
+void loop_allreduce(LoopGroup &g, int rank, const double *send, double *recv, size_t n, hipStream_t s) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  if (cap != hipStreamCaptureStatusNone) raise(MI_ERR_COMM, "the loopback communicator cannot be captured into a graph");
+  MI_HIP(hipStreamSynchronize(s));               // this rank's buffer is complete before it is published
+  g.send[rank] = send;
+  g.barrier();                                   // every rank has published a complete buffer
+  DevBuf<const double *> ptrs;
+  ptrs.upload(g.send.data(), g.send.size(), s);
+  DevBuf<double> tmp(n);                         // in-place calls (recv == send) must not be overwritten while others read
+  const int grid = (int)std::max<size_t>(1, std::min<size_t>((n + NT - 1) / NT, 1024));
+  hipLaunchKernelGGL(k_loop_sum, dim3(grid), dim3(NT), 0, s, n, g.n, ptrs.p, tmp.p);
+  MI_HIP(hipGetLastError());
+  MI_HIP(hipStreamSynchronize(s));               // done reading everyone's buffer
+  g.barrier();                                   // nobody overwrites a send buffer before all ranks have read it
+  MI_HIP(hipMemcpyAsync(recv, tmp.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  MI_HIP(hipStreamSynchronize(s));
+}
+
 static int run_solver(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W, int64_t nvec, int64_t maxit,
                       double eps, double *res_norm, int64_t res_cap, int64_t *it, bool want_M, bool want_W) {
   if (!A || !A->impl || !b || !x || !it || res_cap < 0 || (res_cap > 0 && !res_norm) || maxit < 0)
@@ -276,6 +304,27 @@ int mi_ctx_comm_init(mi_ctx_t ctx, const void *id, int rank, int n_ranks) {
     MI_HIP(hipStreamSynchronize(ctx->stream));
     return MI_OK;
   });
+}
+
+// In-process "ranks" for single-GPU testing of the sharded paths (see LoopGroup in common.hpp).
+int mi_loopback_group_create(int n_ranks, void **group) {
+  if (!group || n_ranks < 1 || n_ranks > 64) return fail(MI_ERR_BAD_ARG, "bad loopback group arguments");
+  return guarded([&]() -> int { *group = new LoopGroup(n_ranks); return MI_OK; });
+}
+int mi_loopback_group_destroy(void *group) {
+  if (!group) return MI_OK;
+  LoopGroup *g = static_cast<LoopGroup *>(group);
+  for (auto e : g->ready) if (e) (void)hipEventDestroy(e);
+  delete g;
+  return MI_OK;
+}
+int mi_ctx_loopback_init(mi_ctx_t ctx, void *group, int rank) {
+  LoopGroup *g = static_cast<LoopGroup *>(group);
+  if (!ctx || !g || rank < 0 || rank >= g->n || ctx->comm) return fail(MI_ERR_BAD_ARG, "bad loopback arguments");
+  ctx->loop = g; ctx->rank = rank; ctx->n_ranks = g->n;
+  ctx->no_graph = true;  // the loopback collective synchronises with the host
+  for (auto &kv : ctx->workspaces) kv.second->drop_graphs();
+  return MI_OK;
 }
 
 int mi_ctx_comm_destroy(mi_ctx_t ctx) {

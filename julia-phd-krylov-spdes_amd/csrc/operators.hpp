@@ -218,7 +218,7 @@ struct LocalMaps {
     ndl = (int)(d1 - d0);
     // An operator that holds EVERY subdomain is replicated, not sharded: it never communicates, even on a context
     // with a communicator. MI355_FORCE_REDUCE=1 keeps the collective anyway (single-GPU rehearsal of the sharded path).
-    sharded = c->comm != nullptr && (!(d0 == 0 && d1 == ndom) || env_int("MI355_FORCE_REDUCE", 0));
+    sharded = c->has_comm() && (!(d0 == 0 && d1 == ndom) || env_int("MI355_FORCE_REDUCE", 0));
     int64_t tot = 0;
     for (int64_t d = d0; d < d1; ++d) {
       if (n_gamma_d[d] < 0 || n_gamma_d[d] > n_gamma) raise(MI_ERR_BAD_ARG, "n_gamma_d[%lld] out of range", (long long)d);
@@ -251,10 +251,31 @@ struct LocalMaps {
     // slot form of the same index for the dense operators: local row -> g*W + j, j = rank of the
     // subdomain among the contributors of Γ node g
     for (int64_t i = 0; i < n_gamma; ++i) slot_width = std::max(slot_width, cntv[i + 1] - cntv[i]);
-    if (slot_width == 3) slot_width = 4;  // 32-byte aligned slot rows -> one double4 load
     std::vector<int> op(nloc);
-    for (int64_t i = 0; i < n_gamma; ++i)
-      for (int k = cntv[i]; k < cntv[i + 1]; ++k) op[pos[k]] = (int)(i * slot_width + (k - cntv[i]));
+    // A slice of the subdomains (multi-GPU): slot j of node g must be the rank of the subdomain among ALL contributors
+    // of g, on every rank alike — then the ranks' slot tables are disjoint (their sum is a union, x + 0) and have one
+    // width. The gather lists of the other ranks' subdomains are index arrays every rank has (set_subdomains is global);
+    // if a caller leaves them NULL the local ranks are used: still a correct sum, but colliding slots are added by the
+    // all-reduce (no longer the single-GPU order) and all ranks must then happen to agree on the width.
+    bool global_slots = ndl < ndom;
+    for (int64_t d = 0; d < ndom && global_slots; ++d) global_slots = !(n_gamma_d[d] > 0 && !gather_idx[d]);
+    if (global_slots) {
+      std::vector<int> seen_cnt((size_t)n_gamma, 0);
+      for (int64_t d = 0; d < ndom; ++d)
+        for (int64_t l = 0; l < n_gamma_d[d]; ++l) {
+          const int g = to_i32(gather_idx[d][l] - base, 0, n_gamma, "gather_idx");
+          const int j = seen_cnt[g]++;
+          if (d >= d0 && d < d1) op[loc_off[d - d0] + l] = j;  // slot rank for now, position below
+        }
+      slot_width = 1;
+      for (int64_t i = 0; i < n_gamma; ++i) slot_width = std::max(slot_width, seen_cnt[i]);
+      if (slot_width == 3) slot_width = 4;
+      for (int s = 0; s < nloc; ++s) op[s] = gidx_h[s] * slot_width + op[s];
+    } else {
+      if (slot_width == 3) slot_width = 4;  // 32-byte aligned slot rows -> one double4 load
+      for (int64_t i = 0; i < n_gamma; ++i)
+        for (int k = cntv[i]; k < cntv[i + 1]; ++k) op[pos[k]] = (int)(i * slot_width + (k - cntv[i]));
+    }
     out_pos.upload(op, c->stream);
     // folded PCG: for local position `loc` of Γ node g with contributors loc_0 < loc_1 < ... (ascending subdomain):
     //   jrank[loc] = my rank among them; peer[loc*W+k] = loc_k; tgt[loc*W+k] = loc_k*W + jrank[loc]
@@ -373,10 +394,12 @@ struct DenseBlockOp : Operator {
   }
   void apply(const double *x, double *y, const int *done) override {
     gemv(x, done);
+    // Multi-GPU: the slot tables of the ranks are disjoint, so their sum is the full table and the Γ-sum below runs in
+    // the single-GPU order (reducing y instead would add per-rank partial sums: same value, different rounding).
+    if (reduce_over_ranks) ctx->allreduce(yslots.p, yslots_all.p, (size_t)n * maps.slot_width);
     hipLaunchKernelGGL(k_assemble_slots, dim3(vec_grid(n)), dim3(NT), 0, ctx->stream, (int)n, maps.slot_width,
-                       yslots.p, y, done);
+                       reduce_over_ranks ? yslots_all.p : yslots.p, y, done);
     MI_HIP(hipGetLastError());
-    if (reduce_over_ranks) ctx->allreduce(y, (size_t)n);
   }
   DenseBlockOp *as_dense() override { return this; }
   static constexpr int KV = 4;  // columns per pass of apply_multi (4 x 16 KiB of LDS for the operand panels)

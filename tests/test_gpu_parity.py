@@ -519,3 +519,68 @@ def test_apply_local_schur_single_subdomain(pkg, ctx, ragged):
             S_d = api.LocalSchur(ctx, P.A_IIdd[d], P.A_IΓdd[d], P.A_ΓΓdd[d], solver, reltol=1e-11)
             got = api.apply_local_schur(S_d, xd)
             assert np.linalg.norm(got - want) <= tol * np.linalg.norm(want)
+
+
+@pytest.mark.parametrize("world,replicate_precond", [(2, True), (2, False), (4, True), (3, False)])
+def test_sharded_operators_with_in_process_ranks(pkg, orc, fem, world, replicate_precond):
+    """SURVEY.md §8(e) on ONE GPU: `world` contexts of this process, one thread each, joined by the loopback communicator
+    (RCCL refuses two ranks on a device). Every rank builds its slice of the subdomains (`dom_slice`), S is sharded, the
+    NN blocks are replicated (bench.py's default) or sharded too; all ranks must return the SAME bits, equal to the
+    single-context 4-launch loop (the slot-table sum over ranks is a union: x + 0), and match the oracle."""
+    import os
+    import threading
+    api = pkg.api
+    N, px, py = 90, 4, 2
+    mesh = fem.get_mesh(N)
+    coeff = lognormal_coeff(fem, mesh.points, 5)
+    P = fem.build_schur_problem(N, px, py, coeff, f_m1, u0734)
+    ndom, n, b = P.sub.ndom, P.sub.n_Γ, P.b_schur
+    gi, cnt = P.sub.gather_idx, P.sub.node_Γ_cnt
+    group = api.LoopbackGroup(world)
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            ctx = api.Context(0)
+            ctx.loopback_init(group, r)
+            lo, hi = api.shard_domains(ndom, r, world)
+            Sd = [P.Sd[d] if lo <= d < hi else None for d in range(ndom)]
+            S = api.LocalSchurs(ctx, Sd, gi, cnt, dom_slice=(lo, hi))
+            if replicate_precond:
+                M = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, gi, cnt, dom_slice=(0, ndom))
+            else:
+                Pd = [P.ΠSd[d] if lo <= d < hi else None for d in range(ndom)]
+                M = api.NeumannNeumannSchurPreconditioner(ctx, Pd, gi, cnt, dom_slice=(lo, hi))
+            y = S * b                                            # a sharded apply: every rank gets the full Γ vector
+            res = api.pcg(S, b, np.zeros(n), M)
+            res_cg = api.cg(S, b, np.zeros(n), maxit=25)
+            out[r] = (y, res, res_cg)
+        except Exception as e:                                   # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errs, errs
+    assert all(o is not None for o in out), "a rank did not finish"
+    for r in range(1, world):                                    # ranks stay bit-identical
+        assert np.array_equal(out[r][0], out[0][0])
+        assert out[r][1][1] == out[0][1][1] and np.array_equal(out[r][1][2], out[0][1][2]) and np.array_equal(out[r][1][0], out[0][1][0])
+        assert np.array_equal(out[r][2][0], out[0][2][0])
+    # single context, same (unfolded) loop: identical bits; and the oracle to the usual bar
+    ctx1 = api.Context(0)
+    S1 = api.LocalSchurs(ctx1, P.Sd, gi, cnt)
+    M1 = api.NeumannNeumannSchurPreconditioner(ctx1, P.ΠSd, gi, cnt)
+    assert np.array_equal(out[0][0], S1 * b)
+    os.environ["MI355_NO_FOLD"] = "1"
+    try:
+        ref = api.pcg(S1, b, np.zeros(n), M1)
+        ref_cg = api.cg(S1, b, np.zeros(n), maxit=25)
+    finally:
+        del os.environ["MI355_NO_FOLD"]
+    assert out[0][1][1] == ref[1] and np.array_equal(out[0][1][2], ref[2]) and np.array_equal(out[0][1][0], ref[0])
+    assert np.array_equal(out[0][2][2], ref_cg[2])
+    So, Mo = orc_ops(orc, P)
+    assert_history(out[0][1], orc.pcg(So, b, np.zeros(n), Mo))

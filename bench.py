@@ -283,7 +283,7 @@ def main():
         return float(np.median(ts))
 
     short = max(2, min(5, its - 2))
-    folded = not multi and its > short + 2
+    folded = (not multi or not args.shard_precond) and its > short + 2   # S sharded + NN replicated also runs the folded loop
     k_us = None
     if folded:
         t_short = gpu_ms(short)
@@ -307,6 +307,8 @@ def main():
         bytes_launch = bytes_dom
     else:
         kname = "k_gemv_pcg (S-apply / NN-apply GEMV with the PCG update folded in; average of both phases)"
+        if multi:
+            kname += "; N>1: half an iteration, i.e. including half of the all-reduce that follows the sharded S launch"
     if kname.startswith("k_gemv_pcg"):
         traffic = pmc_table.get("dominant_kernel_bytes_per_launch")
     else:

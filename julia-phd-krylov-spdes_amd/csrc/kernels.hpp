@@ -367,7 +367,7 @@ struct GemvTile {
   long long mat_off;  // element offset of the subdomain block
   int n, ld;          // n_Γd and padded leading dimension
   int loc_off, row0;  // offset of the block in the local index space, first row of this tile
-  int pad0, pad1;
+  int active, pad1;   // 0: the block of this subdomain lives on another rank (multi-GPU): nothing to stream here
 };
 struct DenseMeta {
   const double *M;        // all blocks of this rank, row-major, padded
@@ -456,6 +456,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_batched(DenseMeta m, const 
   if (done && *done) return;
   __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
   const GemvTile t = m.tiles[blockIdx.x];
+  if (!t.active) return;
   const int off = t.loc_off, n = t.n;
   if (zero_x && *zero_x) {  // x is identically zero (set-up of a solve from x0 = 0): the products are +0, nothing to stream
     const int row_base = t.row0 + (threadIdx.x >> 6) * RPW;
@@ -531,6 +532,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_multi(DenseMeta m, const do
   constexpr int NTH = 64 * WAVES;
   __shared__ __attribute__((aligned(16))) double xs[KV][GEMV_PANEL];
   const GemvTile t = m.tiles[blockIdx.x];
+  if (!t.active) return;
   const int off = t.loc_off, n = t.n, lane = threadIdx.x & 63;
   const int row_base = t.row0 + (threadIdx.x >> 6) * RPW;
   const double *rowp[RPW];
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   if (threadIdx.x < NR) { rowc0[threadIdx.x] = 0.0; rowv[threadIdx.x] = 0.0; }  // visible after the barrier of the sums
   GemvRows<RPW> rows;
 #if !MI355_OPERAND_FIRST
-  rows.begin(m, t);  // matrix stream in flight from here on
+  if (t.active) rows.begin(m, t);  // matrix stream in flight from here on
 #endif
 
   // ---- every load of the prologue is issued before the first barrier (one memory round trip), all contiguous
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   }
 
 #if MI355_OPERAND_FIRST
-  rows.begin(m, t);  // matrix stream in flight from here on: issued AFTER the prologue's loads (results return in issue order)
+  if (t.active) rows.begin(m, t);  // matrix stream in flight from here on: issued AFTER the prologue's loads (results return in issue order)
 #endif
   // ---- scalars
   double coef;  // alpha (PHASE 1) or beta (PHASE 0)
@@ -805,6 +807,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     }
   }
   __syncthreads();
+  // Multi-GPU, sharded S: a tile whose block lives on another rank has done its share of the vector work (scalars,
+  // owner stores of p / r) and stops here; its contribution rows and partial dot come from the owning rank through the
+  // all-reduce that follows the launch (its own entries stay zero).
+  if (PHASE == 0 && !t.active) return;  // (the host only shards the S launch; the ΠS launch needs all tiles)
   rows.panel(xs, 0, t.ld);
   double sum[RPW];
   rows.finish(sum);

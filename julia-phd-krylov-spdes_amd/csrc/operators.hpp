@@ -309,10 +309,17 @@ struct DenseBlockOp : Operator {
   bool scale;  // true: Neumann-Neumann (gather r/cnt, result /cnt)
   int rpw, waves, ntiles = 0, max_nd = 0, max_ld = 0;  // rows per wave, waves per workgroup (4, 8 or 16)
   bool reduce_over_ranks = false;          // this rank holds only a slice of the subdomains and a communicator exists
+  bool full_maps = false;                  // ... and is built on the maps of all subdomains (inactive tiles for the others)
   DevBuf<double> M, cnt, yslots;
   DevBuf<double> yslots_all;  // multi-GPU: all-reduced copy of the contribution slots (every rank's subdomains)
-  DevBuf<double> fold_part0, fold_part1;  // per-tile partial dots of the folded PCG launches
-  DevBuf<double> fold_con, fold_vec;      // [nloc*W] local-order contributions; [4*nloc] r/p current+next copies
+  // folded PCG launches: [nloc*W] local-order contributions followed by the per-tile partials of the first dot, in ONE
+  // buffer (`fold_pack`; `fold_pack_all` = its sum over ranks when the launch is sharded); second partial array; [4*nloc]
+  // r/p current+next copies
+  DevBuf<double> fold_pack, fold_pack_all, fold_part1, fold_vec;
+  size_t fold_con_n = 0, fold_pack_n = 0;
+  double *fold_con(bool reduced = false) const { return (reduced ? fold_pack_all.p : fold_pack.p); }
+  double *fold_part0(bool reduced = false) const { return (reduced ? fold_pack_all.p : fold_pack.p) + fold_con_n; }
+  void reduce_fold() { ctx->allreduce(fold_pack.p, fold_pack_all.p, fold_pack_n); }
   DevBuf<GemvTile> tiles;
   int64_t alg_bytes = 0;
   DenseMeta meta{};
@@ -321,10 +328,17 @@ struct DenseBlockOp : Operator {
                const double *const *blocks, const int64_t *node_cnt, int base, int64_t d0, int64_t d1)
       : Operator(c, n_gamma), scale(node_cnt != nullptr) {
     if (!blocks) raise(MI_ERR_BAD_ARG, "dense blocks pointer is NULL");
-    maps.build(c, ndom, n_gamma, n_gamma_d, gather_idx, base, d0, d1);
+    // A slice of the subdomains (multi-GPU) is built on the maps of ALL subdomains whenever their gather lists are given
+    // (index arrays every rank has): tiles of the other ranks' blocks exist but are inactive. The slot tables of the
+    // ranks are then disjoint by construction, and the folded PCG launches can run sharded (solvers.hpp).
+    full_maps = true;
+    for (int64_t d = 0; d < ndom && full_maps; ++d) full_maps = !(n_gamma_d && n_gamma_d[d] > 0 && gather_idx && !gather_idx[d]);
+    const int64_t m0 = full_maps ? 0 : d0, m1 = full_maps ? ndom : d1;
+    maps.build(c, ndom, n_gamma, n_gamma_d, gather_idx, base, m0, m1);
     // Replicated operators (every subdomain present) never communicate — e.g. the Neumann-Neumann blocks copied to
     // all ranks while S is sharded, which halves the all-reduces of a multi-GPU PCG iteration.
-    reduce_over_ranks = maps.sharded;
+    reduce_over_ranks = c->has_comm() && (!(d0 == 0 && d1 == ndom) || env_int("MI355_FORCE_REDUCE", 0));
+    maps.sharded = reduce_over_ranks;
     rpw = env_int("MI355_GEMV_RPW", 2);
     if (rpw != 1 && rpw != 2 && rpw != 4) rpw = 2;
     waves = env_int("MI355_GEMV_WAVES", 16);
@@ -333,27 +347,32 @@ struct DenseBlockOp : Operator {
     std::vector<int> ldv;
     std::vector<GemvTile> tv;
     long long tot = 0;
+    auto owned = [&](int dl) { return m0 + dl >= d0 && m0 + dl < d1; };
     for (int dl = 0; dl < maps.ndl; ++dl) {
       const int n_d = maps.nd[dl];
       int l = (n_d + 15) / 16 * 16;
       // A row stride that is a multiple of 2 KiB puts every row of a tile on the same HBM channels: measured 27 % slower
       // at n_Γd = 1024 (profiles/r01_gemv_variant_sweep.txt). One extra 128-byte line per row breaks the pattern.
       if (l % 256 == 0 && l != GEMV_PANEL) l += 16;
-      if (n_d && !blocks[d0 + dl]) raise(MI_ERR_BAD_ARG, "dense block %d is NULL", dl);
-      moff.push_back(tot); ldv.push_back(l);
+      const bool own = owned(dl);
+      if (own && n_d && !blocks[m0 + dl]) raise(MI_ERR_BAD_ARG, "dense block %d is NULL", dl);
+      moff.push_back(own ? tot : 0); ldv.push_back(l);
       max_nd = std::max(max_nd, n_d);
       max_ld = std::max(max_ld, l);
-      for (int r = 0; r < n_d; r += waves * rpw) tv.push_back(GemvTile{tot, n_d, l, maps.loc_off[dl], r, 0, 0});
-      tot += (long long)n_d * l;
-      alg_bytes += 8ll * n_d * n_d + 16ll * n_d + 4ll * n_d;
+      for (int r = 0; r < n_d; r += waves * rpw) tv.push_back(GemvTile{own ? tot : 0, n_d, l, maps.loc_off[dl], r, own ? 1 : 0, 0});
+      if (own) {
+        tot += (long long)n_d * l;
+        alg_bytes += 8ll * n_d * n_d + 16ll * n_d + 4ll * n_d;
+      }
     }
     ntiles = (int)tv.size();
     M.alloc((size_t)tot);
     // column-major (Julia) -> padded row-major, one block at a time
     for (int dl = 0; dl < maps.ndl; ++dl) {
+      if (!owned(dl)) continue;
       const int n_d = maps.nd[dl], l = ldv[dl];
       std::vector<double> rowm((size_t)n_d * l, 0.0);
-      const double *src = blocks[d0 + dl];
+      const double *src = blocks[m0 + dl];
       for (int j = 0; j < n_d; ++j)
         for (int i = 0; i < n_d; ++i) rowm[(size_t)i * l + j] = src[(size_t)i + (size_t)j * n_d];
       if (!rowm.empty())
@@ -373,9 +392,12 @@ struct DenseBlockOp : Operator {
     yslots.zero(c->stream);  // unused slots (and, multi-GPU, the other ranks' slots) stay 0 for the lifetime of the operator
     yslots_all.alloc((size_t)n_gamma * maps.slot_width + 4);
     yslots_all.zero(c->stream);
-    fold_part0.alloc((size_t)ntiles + 1); fold_part1.alloc((size_t)ntiles + 1);
-    fold_part0.zero(c->stream); fold_part1.zero(c->stream);
-    fold_con.alloc((size_t)maps.nloc * maps.slot_width + 4); fold_con.zero(c->stream);
+    // contributions and first partial-dot array share one buffer: the sharded S launch all-reduces both in one call
+    fold_con_n = (size_t)maps.nloc * maps.slot_width + 4;
+    fold_pack_n = fold_con_n + (size_t)ntiles + 1;
+    fold_pack.alloc(fold_pack_n); fold_pack.zero(c->stream);
+    fold_pack_all.alloc(fold_pack_n); fold_pack_all.zero(c->stream);
+    fold_part1.alloc((size_t)ntiles + 1); fold_part1.zero(c->stream);
     fold_vec.alloc((size_t)maps.nloc * 4 + 4); fold_vec.zero(c->stream);
     MI_HIP(hipStreamSynchronize(c->stream));
     meta = DenseMeta{M.p, tiles.p, maps.gidx.p, scale ? cnt.p : nullptr, maps.out_pos.p};

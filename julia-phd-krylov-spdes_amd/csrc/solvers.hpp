@@ -166,7 +166,9 @@ struct Krylov {
         fused(!generic && A_->n <= FUSED_MAX_N && !env_int("MI355_NO_FUSED", 0)), fold(false) {
     if (fused && allow_fold && M && nvec == 0 && !env_int("MI355_NO_FOLD", 0)) {
       Ad = A->as_dense(); Md = M->as_dense();
-      fold = Ad && Md && !Ad->reduce_over_ranks && !Md->reduce_over_ranks &&
+      // multi-GPU: S may be sharded (built on the maps of all subdomains, inactive tiles for the other ranks' blocks)
+      // while the Neumann-Neumann blocks are replicated: the S launch is then followed by one all-reduce
+      fold = Ad && Md && (!Ad->reduce_over_ranks || Ad->full_maps) && !Md->reduce_over_ranks &&
              !Ad->scale && Md->scale && Ad->same_maps(*Md) && Ad->ntiles > 0 && Ad->max_ld <= GEMV_PANEL && Ad->maps.slot_width <= 4 &&
              (Ad->max_ld + 64 * Ad->waves - 1) / (64 * Ad->waves) <= 8;
     }
@@ -178,14 +180,15 @@ struct Krylov {
     f.r_cur = Ad->fold_vec.p; f.r_nxt = f.r_cur + nl; f.p_cur = f.r_nxt + nl; f.p_nxt = f.p_cur + nl;
     f.tgt = Ad->maps.tgt.p; f.peer = Ad->maps.peer.p; f.jrank = Ad->maps.jrank.p;
     f.n_in = Ad->ntiles;
+    const bool red = Ad->reduce_over_ranks;  // the S launch's outputs are summed over the ranks before the ΠS launch reads them
     if (phase) {  // ΠS launch: reads S contributions + partial p'Ap, writes ΠS contributions + partial r'r, r'z
-      f.con_in = Ad->fold_con.p; f.con_out = Md->fold_con.p;
-      f.part_in0 = Ad->fold_part0.p; f.part_in1 = nullptr;
-      f.part_out0 = Md->fold_part0.p; f.part_out1 = Md->fold_part1.p;
+      f.con_in = Ad->fold_con(red); f.con_out = Md->fold_con();
+      f.part_in0 = Ad->fold_part0(red); f.part_in1 = nullptr;
+      f.part_out0 = Md->fold_part0(); f.part_out1 = Md->fold_part1.p;
     } else {      // S launch: reads ΠS contributions + partial r'r, r'z, writes S contributions + partial p'Ap
-      f.con_in = Md->fold_con.p; f.con_out = Ad->fold_con.p;
-      f.part_in0 = Md->fold_part0.p; f.part_in1 = Md->fold_part1.p;
-      f.part_out0 = Ad->fold_part0.p; f.part_out1 = nullptr;
+      f.con_in = Md->fold_con(); f.con_out = Ad->fold_con();
+      f.part_in0 = Md->fold_part0(); f.part_in1 = Md->fold_part1.p;
+      f.part_out0 = Ad->fold_part0(); f.part_out1 = nullptr;
     }
     return f;
   }
@@ -241,6 +244,7 @@ struct Krylov {
       // 2 launches per iteration: (alpha, x, r, z, r'z, r'r) in the ΠS GEMV; (stop rule, beta, p, Ap, p'Ap) in the S GEMV
       Md->gemv_pcg(1, fold_args(1));
       Ad->gemv_pcg(0, fold_args(0));
+      if (Ad->reduce_over_ranks) Ad->reduce_fold();  // S contributions + partial p'Ap: union over the ranks
       return;
     }
     if (fused) {

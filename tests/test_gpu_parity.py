@@ -304,16 +304,18 @@ def test_rccl_single_rank_communicator(pkg, ctx, orc, micro):
     Mr = api.NeumannNeumannSchurPreconditioner(c2, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)   # replicated: no collective
     got = api.pcg(S, P.b_schur, np.zeros(n), M)
     assert_history(got, orc.pcg(So, P.b_schur, np.zeros(n), Mo))
-    # Summing with the other ranks' zeros is exact, so the sharded loop is bit-identical to the 4-launch loop
-    # without a communicator — whether the preconditioner is sharded too or replicated on every rank.
+    # Summing with the other ranks' zeros is exact, so a sharded loop is bit-identical to the same loop form without a
+    # communicator: the 4-launch loop when the preconditioner is sharded too, the folded loop (S launch + one captured
+    # all-reduce + ΠS launch) when it is replicated on every rank.
     S1, M1 = gpu_ops(pkg, ctx, P)
+    ref_fold = api.pcg(S1, P.b_schur, np.zeros(n), M1)
     os.environ["MI355_NO_FOLD"] = "1"
     try:
         ref = api.pcg(S1, P.b_schur, np.zeros(n), M1)
     finally:
         del os.environ["MI355_NO_FOLD"]
-    for other in (got, api.pcg(S, P.b_schur, np.zeros(n), Mr)):
-        assert other[1] == ref[1] and np.array_equal(other[2], ref[2]) and np.array_equal(other[0], ref[0])
+    for other, want in ((got, ref), (api.pcg(S, P.b_schur, np.zeros(n), Mr), ref_fold)):
+        assert other[1] == want[1] and np.array_equal(other[2], want[2]) and np.array_equal(other[0], want[0])
     v = np.random.default_rng(1).standard_normal(n)
     assert np.array_equal(S * v, S1 * v) and np.array_equal(M.ldiv(v), M1.ldiv(v)) and np.array_equal(Mr.ldiv(v), M1.ldiv(v))
     # a fully replicated pair on a context with a communicator is free to use the folded loop
@@ -521,12 +523,12 @@ def test_apply_local_schur_single_subdomain(pkg, ctx, ragged):
             assert np.linalg.norm(got - want) <= tol * np.linalg.norm(want)
 
 
-@pytest.mark.parametrize("world,replicate_precond", [(2, True), (2, False), (4, True), (3, False)])
+@pytest.mark.parametrize("world,replicate_precond", [(2, True), (2, False), (4, True), (3, False), (8, True)])
 def test_sharded_operators_with_in_process_ranks(pkg, orc, fem, world, replicate_precond):
     """SURVEY.md §8(e) on ONE GPU: `world` contexts of this process, one thread each, joined by the loopback communicator
     (RCCL refuses two ranks on a device). Every rank builds its slice of the subdomains (`dom_slice`), S is sharded, the
     NN blocks are replicated (bench.py's default) or sharded too; all ranks must return the SAME bits, equal to the
-    single-context 4-launch loop (the slot-table sum over ranks is a union: x + 0), and match the oracle."""
+    single-context loop of the same form (the sums over ranks are unions: x + 0), and match the oracle."""
     import os
     import threading
     api = pkg.api
@@ -554,7 +556,11 @@ def test_sharded_operators_with_in_process_ranks(pkg, orc, fem, world, replicate
             y = S * b                                            # a sharded apply: every rank gets the full Γ vector
             res = api.pcg(S, b, np.zeros(n), M)
             res_cg = api.cg(S, b, np.zeros(n), maxit=25)
-            out[r] = (y, res, res_cg)
+            ymf = None
+            if world == 2:                                       # the matrix-free operator, sharded the same way
+                Smf = api.MatrixFreeLocalSchurs(ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, gi, cnt, P.solvers, dom_slice=(lo, hi))
+                ymf = Smf * b
+            out[r] = (y, res, res_cg, ymf)
         except Exception as e:                                   # noqa: BLE001
             errs.append((r, repr(e)))
 
@@ -574,13 +580,19 @@ def test_sharded_operators_with_in_process_ranks(pkg, orc, fem, world, replicate
     S1 = api.LocalSchurs(ctx1, P.Sd, gi, cnt)
     M1 = api.NeumannNeumannSchurPreconditioner(ctx1, P.ΠSd, gi, cnt)
     assert np.array_equal(out[0][0], S1 * b)
-    os.environ["MI355_NO_FOLD"] = "1"
+    # S sharded + NN replicated runs the FOLDED loop across the ranks (one all-reduce after the S launch); with the NN
+    # blocks sharded too the 4-launch loop runs: compare with the same loop form on one context
+    if not replicate_precond:
+        os.environ["MI355_NO_FOLD"] = "1"
     try:
         ref = api.pcg(S1, b, np.zeros(n), M1)
         ref_cg = api.cg(S1, b, np.zeros(n), maxit=25)
     finally:
-        del os.environ["MI355_NO_FOLD"]
+        os.environ.pop("MI355_NO_FOLD", None)
     assert out[0][1][1] == ref[1] and np.array_equal(out[0][1][2], ref[2]) and np.array_equal(out[0][1][0], ref[0])
     assert np.array_equal(out[0][2][2], ref_cg[2])
+    if world == 2:    # matrix-free: per-rank partial Γ-sums are added by the all-reduce (same value, another rounding order)
+        assert np.array_equal(out[0][3], out[1][3])
+        assert np.allclose(out[0][3], out[0][0], rtol=1e-9, atol=1e-11 * np.abs(out[0][0]).max())
     So, Mo = orc_ops(orc, P)
     assert_history(out[0][1], orc.pcg(So, b, np.zeros(n), Mo))

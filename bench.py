@@ -283,7 +283,7 @@ def main():
         return float(np.median(ts))
 
     short = max(2, min(5, its - 2))
-    folded = (not multi or not args.shard_precond) and its > short + 2   # S sharded + NN replicated also runs the folded loop
+    folded = (not multi or not args.shard_precond or world == 1) and its > short + 2   # S sharded + NN replicated also runs the folded loop
     k_us = None
     if folded:
         t_short = gpu_ms(short)
@@ -353,8 +353,9 @@ def main():
                                    f"pcg(S, b_schur, 0, ΠSnn), eps={args.eps:g}",
                        "subdomains_per_gpu": hi - lo,
                        "parallelism": ("single GPU" if not multi else
-                                       f"S sharded {hi - lo} subdomain(s)/GPU + RCCL all-reduce of the slot table; NN blocks "
-                                       + ("sharded (2 all-reduces/iteration)" if args.shard_precond else "replicated (1 all-reduce/iteration)")),
+                                       f"S sharded {hi - lo} subdomain(s)/GPU; NN blocks "
+                                       + ("sharded: 4-launch loop, 2 RCCL all-reduces of the slot tables per iteration" if args.shard_precond
+                                          else "replicated: folded loop, 1 RCCL all-reduce of the S launch's contribution table per iteration")),
                        "it": its, "loop_iterations_per_solve": loop_its,
                        "final_relres": relres, "launches_per_iteration": 2 if folded else 4},
             "roofline": roofline,

@@ -367,7 +367,9 @@ struct GemvTile {
   long long mat_off;  // element offset of the subdomain block
   int n, ld;          // n_Γd and padded leading dimension
   int loc_off, row0;  // offset of the block in the local index space, first row of this tile
-  int active, pad1;   // 0: the block of this subdomain lives on another rank (multi-GPU): nothing to stream here
+  int active, nrows;  // active 0: the block of this subdomain lives on another rank (multi-GPU): nothing to stream here.
+                      // nrows: rows [row0, row0 + nrows) whose owner duties this tile performs in the folded launches
+                      // (active: the WAVES*RPW streamed rows; inactive: up to one row per thread)
 };
 struct DenseMeta {
   const double *M;        // all blocks of this rank, row-major, padded
@@ -645,6 +647,7 @@ struct PcgFold {
   const int *peer;          // [nloc*W] local positions of the same Γ node in the sharing subdomains (-1 pad)
   const int *jrank;         // [nloc] rank of this subdomain among the contributors of the node (0 = owner)
   int W;
+  int part_rows;            // PHASE 0 writes its partial dot per row (local order, nloc entries) instead of per tile
 };
 __device__ __forceinline__ double slot_sum(const double *slots, int g, int W) {
   double s = 0.0;
@@ -684,9 +687,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   const double tol = st->tol, rTz0 = st->rTz, old = st->rTz_prev;
   const bool first1 = PHASE == 1 && it_nxt0 == 0;  // very first launch of a solve: r_0 comes from the Γ-ordered vector, p = 0
   double pa = 0.0, pb = 0.0;
-  for (int i = threadIdx.x; i < f.n_in; i += NTH) {
-    pa += f.part_in0[i];
-    if (PHASE == 0) pb += f.part_in1[i];
+  for (int i0 = threadIdx.x; i0 < f.n_in; i0 += 8 * NTH) {  // up to eight partials in flight per thread, added in order
+    double ta[8], tb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * NTH;
+      ta[k] = i < f.n_in ? f.part_in0[i] : 0.0;
+      tb[k] = PHASE == 0 && i < f.n_in ? f.part_in1[i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { pa += ta[k]; if (PHASE == 0) pb += tb[k]; }
   }
   double cv[FOLD_CPT], cs[FOLD_CPT], cc[FOLD_CPT];  // vector value, Γ-sum of the contributions, cnt — per column
 #pragma unroll
@@ -709,7 +719,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
 #pragma unroll
   for (int q = 0; q < FOLD_CPT; ++q) {
     const int j = q * NTH + threadIdx.x, ri = j - t.row0;
-    if (j < n && ri >= 0 && ri < NR) {
+    if (j < n && ri >= 0 && ri < t.nrows) {
       const int loc = off + j;
       o_q = q;
       // everything an owner needs is requested unconditionally (a load behind `if (owner)` would wait for jrank first:
@@ -786,10 +796,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
       xs[j] = vs;
       if (q == o_q) {
         const int ri = j - t.row0;
-        rowv[ri] = v;
+        if (t.active) rowv[ri] = v;
         if (o_own) {                                      // owner of this Γ node
           if (PHASE == 1) {
-            rowc0[ri] = v * v;
+            if (t.active) rowc0[ri] = v * v;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const int pl = o_peer[k];
@@ -833,6 +843,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   }
   if (PHASE == 1 && o_q >= 0 && o_own) f.x[o_g] = o_x + coef * o_a;  // x + alpha*p (cg.jl:97), off the critical path
   __syncthreads();
+  if (PHASE == 0 && f.part_rows) {
+    // multi-GPU, sharded S: one product per ROW at its local position instead of one partial per tile — a layout that
+    // does not depend on how each rank tiles its blocks, so the ranks' arrays add up to the full one
+    if (threadIdx.x < NR && t.row0 + (int)threadIdx.x < n) f.part_out0[off + t.row0 + threadIdx.x] = rowc1[threadIdx.x];
+    return;
+  }
   if (threadIdx.x < 64) {  // per-tile partials of the next dot products: one shuffle tree over the NR row terms
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < NR; i += 64) { a += rowc1[i]; b += rowc0[i]; }

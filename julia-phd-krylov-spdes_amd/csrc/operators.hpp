@@ -343,6 +343,19 @@ struct DenseBlockOp : Operator {
     if (rpw != 1 && rpw != 2 && rpw != 4) rpw = 2;
     waves = env_int("MI355_GEMV_WAVES", 16);
     if (waves != 4 && waves != 8 && waves != 16) waves = 16;
+    if (reduce_over_ranks && full_maps && !env_int("MI355_GEMV_WAVES", 0) && !env_int("MI355_GEMV_RPW", 0)) {
+      // A rank that owns 1/N of the blocks would keep 1/N of the CUs busy with 32-row tiles (a launch lasts as long as
+      // one tile): cut the owned rows into about one tile per CU instead.
+      int64_t owned_rows = 0;
+      for (int64_t d = d0; d < d1; ++d) owned_rows += n_gamma_d[d];
+      hipDeviceProp_t prop;
+      MI_HIP(hipGetDeviceProperties(&prop, c->device));
+      const int64_t per_tile = std::max<int64_t>(1, owned_rows / std::max(1, prop.multiProcessorCount));
+      if (per_tile >= 24) { waves = 16; rpw = 2; }
+      else if (per_tile >= 12) { waves = 16; rpw = 1; }
+      else if (per_tile >= 6) { waves = 8; rpw = 1; }
+      else { waves = 4; rpw = 1; }
+    }
     std::vector<long long> moff;
     std::vector<int> ldv;
     std::vector<GemvTile> tv;
@@ -359,7 +372,10 @@ struct DenseBlockOp : Operator {
       moff.push_back(own ? tot : 0); ldv.push_back(l);
       max_nd = std::max(max_nd, n_d);
       max_ld = std::max(max_ld, l);
-      for (int r = 0; r < n_d; r += waves * rpw) tv.push_back(GemvTile{own ? tot : 0, n_d, l, maps.loc_off[dl], r, own ? 1 : 0, 0});
+      // tiles of another rank's block only do owner duties in the folded launches: as few workgroups as possible
+      const int step = own ? waves * rpw : 64 * waves;
+      for (int r = 0; r < n_d; r += step)
+        tv.push_back(GemvTile{own ? tot : 0, n_d, l, maps.loc_off[dl], r, own ? 1 : 0, std::min(step, n_d - r)});
       if (own) {
         tot += (long long)n_d * l;
         alg_bytes += 8ll * n_d * n_d + 16ll * n_d + 4ll * n_d;
@@ -394,7 +410,7 @@ struct DenseBlockOp : Operator {
     yslots_all.zero(c->stream);
     // contributions and first partial-dot array share one buffer: the sharded S launch all-reduces both in one call
     fold_con_n = (size_t)maps.nloc * maps.slot_width + 4;
-    fold_pack_n = fold_con_n + (size_t)ntiles + 1;
+    fold_pack_n = fold_con_n + std::max<size_t>((size_t)ntiles + 1, (size_t)maps.nloc + 1);  // per-tile, or per-row when sharded
     fold_pack.alloc(fold_pack_n); fold_pack.zero(c->stream);
     fold_pack_all.alloc(fold_pack_n); fold_pack_all.zero(c->stream);
     fold_part1.alloc((size_t)ntiles + 1); fold_part1.zero(c->stream);
@@ -457,8 +473,8 @@ struct DenseBlockOp : Operator {
     MI_HIP(hipGetLastError());
   }
   bool same_maps(const DenseBlockOp &o) const {
-    return n == o.n && rpw == o.rpw && waves == o.waves && ntiles == o.ntiles && maps.slot_width == o.maps.slot_width &&
-           maps.nd == o.maps.nd && maps.gidx_h == o.maps.gidx_h;
+    // (the tilings may differ: a sharded S cuts its few blocks into more, smaller tiles)
+    return n == o.n && maps.slot_width == o.maps.slot_width && maps.nd == o.maps.nd && maps.gidx_h == o.maps.gidx_h;
   }
   AsmView view_of(double *) override {
     return reduce_over_ranks ? AsmView{yslots_all.p, maps.slot_width} : AsmView{yslots.p, maps.slot_width};

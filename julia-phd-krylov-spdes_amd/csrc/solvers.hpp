@@ -170,7 +170,7 @@ struct Krylov {
       // while the Neumann-Neumann blocks are replicated: the S launch is then followed by one all-reduce
       fold = Ad && Md && (!Ad->reduce_over_ranks || Ad->full_maps) && !Md->reduce_over_ranks &&
              !Ad->scale && Md->scale && Ad->same_maps(*Md) && Ad->ntiles > 0 && Ad->max_ld <= GEMV_PANEL && Ad->maps.slot_width <= 4 &&
-             (Ad->max_ld + 64 * Ad->waves - 1) / (64 * Ad->waves) <= 8;
+             (Ad->max_ld + 64 * Ad->waves - 1) / (64 * Ad->waves) <= 8 && (Md->max_ld + 64 * Md->waves - 1) / (64 * Md->waves) <= 8;
     }
   }
   PcgFold fold_args(int phase) const {
@@ -179,7 +179,9 @@ struct Krylov {
     f.st = ws.st; f.W = Ad->maps.slot_width; f.res_norm = ws.res_norm.p; f.x = ws.x; f.r_gamma = ws.r;
     f.r_cur = Ad->fold_vec.p; f.r_nxt = f.r_cur + nl; f.p_cur = f.r_nxt + nl; f.p_nxt = f.p_cur + nl;
     f.tgt = Ad->maps.tgt.p; f.peer = Ad->maps.peer.p; f.jrank = Ad->maps.jrank.p;
-    f.n_in = Ad->ntiles;
+    // partial-dot arrays of the OTHER operator's launch (tilings may differ); a sharded S writes one product per row
+    f.part_rows = Ad->reduce_over_ranks ? 1 : 0;
+    f.n_in = phase ? (f.part_rows ? Ad->maps.nloc : Ad->ntiles) : Md->ntiles;
     const bool red = Ad->reduce_over_ranks;  // the S launch's outputs are summed over the ranks before the ΠS launch reads them
     if (phase) {  // ΠS launch: reads S contributions + partial p'Ap, writes ΠS contributions + partial r'r, r'z
       f.con_in = Ad->fold_con(red); f.con_out = Md->fold_con();

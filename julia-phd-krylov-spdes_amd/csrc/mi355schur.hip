@@ -191,7 +191,7 @@ using namespace mi;
 
 extern "C" {
 
-int mi_version(void) { return 100; }  // 0.1.0
+int mi_version(void) { return 200; }  // 0.2.0
 const char *mi_last_error(void) { return last_error().c_str(); }
 
 int mi_device_count(int *count) {

@@ -603,3 +603,56 @@ def test_sharded_operators_with_in_process_ranks(pkg, orc, fem, world, replicate
         assert np.allclose(out[0][3], out[0][0], rtol=1e-9, atol=1e-11 * np.abs(out[0][0]).max())
     So, Mo = orc_ops(orc, P)
     assert_history(out[0][1], orc.pcg(So, b, np.zeros(n), Mo))
+
+
+def test_sharded_deflated_and_recycling_solvers_with_in_process_ranks(pkg, orc, fem):
+    """defpcg / eigpcg / eigdefpcg on 2 in-process ranks (S sharded, NN replicated): these run the 4-launch loop with an
+    all-reduce of the slot table after every S-apply (also for `WtA = (A W)'` and eigpcg's `A*V`). All ranks identical,
+    and equal to the single-context run: bit for bit for defpcg (same kernels, union of slot tables), to the recycled-space
+    bar for the eig solvers' vectors."""
+    import threading
+    from test_gpu_eig import assert_space
+    api = pkg.api
+    N, px, py, world = 60, 3, 2, 2
+    mesh = fem.get_mesh(N)
+    P = fem.build_schur_problem(N, px, py, lognormal_coeff(fem, mesh.points, 9), f_m1, u0734)
+    ndom, n, b = P.sub.ndom, P.sub.n_Γ, P.b_schur
+    gi, cnt = P.sub.gather_idx, P.sub.node_Γ_cnt
+    So, Mo = orc_ops(orc, P)
+    nvec, spdim = int(1.25 * ndom), 3 * ndom
+    W = orc.eigpcg(So, b, np.zeros(n), Mo, nvec, spdim)[3]
+    b2 = So(np.random.default_rng(2).standard_normal(n))
+    group = api.LoopbackGroup(world)
+    out, errs = [None] * world, []
+
+    def solves(S, M):
+        return (api.defpcg(S, b2, np.zeros(n), W, M), api.eigpcg(S, b, np.zeros(n), M, nvec, spdim),
+                api.eigdefpcg(S, b2, np.zeros(n), M, W, spdim))
+
+    def rank_main(r):
+        try:
+            ctx = api.Context(0)
+            ctx.loopback_init(group, r)
+            lo, hi = api.shard_domains(ndom, r, world)
+            S = api.LocalSchurs(ctx, [P.Sd[d] if lo <= d < hi else None for d in range(ndom)], gi, cnt, dom_slice=(lo, hi))
+            M = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, gi, cnt, dom_slice=(0, ndom))
+            out[r] = solves(S, M)
+        except Exception as e:                                   # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errs, errs
+    assert all(o is not None for o in out)
+    for k in range(3):                                           # ranks identical
+        assert out[0][k][1] == out[1][k][1] and np.array_equal(out[0][k][2], out[1][k][2]) and np.array_equal(out[0][k][0], out[1][k][0])
+    ctx1 = api.Context(0)
+    ref = solves(api.LocalSchurs(ctx1, P.Sd, gi, cnt), api.NeumannNeumannSchurPreconditioner(ctx1, P.ΠSd, gi, cnt))
+    assert out[0][0][1] == ref[0][1] and np.allclose(out[0][0][2], ref[0][2], rtol=1e-9, atol=1e-13 * ref[0][2][0])
+    for k in (1, 2):
+        assert out[0][k][1] == ref[k][1] and np.allclose(out[0][k][2], ref[k][2], rtol=1e-8, atol=1e-12 * ref[k][2][0])
+        assert_space(So, out[0][k][3], ref[k][3])
+    assert_history(out[0][0][:3], orc.defpcg(So, b2, np.zeros(n), W, Mo))

@@ -3,7 +3,8 @@
 What shards: subdomains -> ranks (`api.shard_domains`), Γ-vectors replicated, the two
 Γ-sums of every PCG iteration all-reduced. On a GPU box the per-rank partial applies are the HIP
 kernels and the all-reduce is RCCL inside the iteration graph (tests/test_gpu_parity.py covers the
-slices adding up and the captured collective at world_size 1). Here, without a GPU, the per-rank
+captured collective at world_size 1 and — with 2, 3, 4 and 8 in-process ranks joined by the loopback
+communicator on one GPU — the sharded operators and loops themselves). Here, without a GPU, the per-rank
 partial applies are played by the oracle (as the checker) and the all-reduce by gloo, which pins the
 host-side logic: the shard plan, the per-rank problem set-up (`dom_slice`), the b_schur reduction and
 the fact that the replicated-vector algorithm reproduces the single-rank iterates.

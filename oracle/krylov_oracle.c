@@ -299,7 +299,7 @@ orc_op *orc_schur_global_op(i64 ndom, i64 n_gamma, const i64 *n_i,
  * r -= alpha c; prev = residual; residual = ||r||. A symmetric, CSC arrays. Returns the iteration count. */
 i64 orc_interior_cg(i64 n, const i64 *colptr, const i64 *rowval, const double *nzval, const double *b, double *x,
                     double reltol) {
-  double *r = (double *)malloc(sizeof(double) * (size_t)(3 * n + 3));
+  double *r = (double *)calloc((size_t)(3 * n + 3), sizeof(double));
   double *u = r + n, *c = u + n;
   for (i64 i = 0; i < n; ++i) { x[i] = 0.0; r[i] = b[i]; u[i] = 0.0; }
   double residual = orc_norm2(n, r), prev = 1.0;

@@ -210,7 +210,8 @@ def main():
     if args.force_dist and world == 1:
         os.environ["MI355_FORCE_REDUCE"] = "1"   # one-rank rehearsal: keep the collectives of the sharded S
     S = api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(lo, hi))
-    os.environ.pop("MI355_FORCE_REDUCE", None)
+    if not args.shard_precond:
+        os.environ.pop("MI355_FORCE_REDUCE", None)
     if multi and not args.shard_precond:
         # S is sharded (subdomain d on GPU d, one all-reduce per S-apply). The Neumann-Neumann blocks are replicated
         # on every rank instead (68 MB): the NN-apply is then purely local and an iteration needs ONE all-reduce.
@@ -225,6 +226,7 @@ def main():
         M = api.NeumannNeumannSchurPreconditioner(ctx, Pi_all, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(0, ndom))
     else:
         M = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(lo, hi))
+    os.environ.pop("MI355_FORCE_REDUCE", None)
     b_dev = torch.from_numpy(b_host).cuda()
     xs = [torch.zeros(n_Γ, dtype=torch.float64, device="cuda") for _ in range(args.warmup + args.steps)]
     torch.cuda.synchronize()
@@ -283,7 +285,7 @@ def main():
         return float(np.median(ts))
 
     short = max(2, min(5, its - 2))
-    folded = (not multi or not args.shard_precond or world == 1) and its > short + 2   # S sharded + NN replicated also runs the folded loop
+    folded = (not multi or not args.shard_precond) and its > short + 2   # S sharded + NN replicated also runs the folded loop
     k_us = None
     if folded:
         t_short = gpu_ms(short)

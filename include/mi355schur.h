@@ -163,6 +163,14 @@ int mi_schur_global_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const in
                            const double *const *ig_nzval, const int64_t *gg_colptr,
                            const int64_t *gg_rowval, const double *gg_nzval,
                            mi_interior_solve_fn solve, void *user, int index_base, mi_op_t *op);
+/* The same with the interior solves on the device, as for mi_schur_matfree_device_create: `IterativeSolvers.cg(A_IId[idom],
+ * A_IΓd[idom]*x)` (EPDD.jl:609-619) restated; the reference calls it with the package default reltol = sqrt(eps). */
+int mi_schur_global_device_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_i,
+                                  const int64_t *const *ii_colptr, const int64_t *const *ii_rowval,
+                                  const double *const *ii_nzval, const int64_t *const *ig_colptr,
+                                  const int64_t *const *ig_rowval, const double *const *ig_nzval,
+                                  const int64_t *gg_colptr, const int64_t *gg_rowval, const double *gg_nzval,
+                                  double reltol, int index_base, mi_op_t *op);
 
 int mi_op_size(mi_op_t op, int64_t *n);
 /* y = A*x (operator) or y = M \ x (preconditioner); x and y must not alias. */

@@ -53,6 +53,8 @@ SIGNATURES = {
                                        i64pp, i64pp, f64pp, C.c_double, C.c_int, i64, i64, C.POINTER(vp)],
     "mi_schur_global_create": [vp, i64, i64, i64p, i64pp, i64pp, f64pp, i64p, i64p, f64p,
                                INTERIOR_SOLVE_FN, vp, C.c_int, C.POINTER(vp)],
+    "mi_schur_global_device_create": [vp, i64, i64, i64p, i64pp, i64pp, f64pp, i64pp, i64pp, f64pp, i64p, i64p, f64p,
+                                      C.c_double, C.c_int, C.POINTER(vp)],
     "mi_op_size": [vp, i64p],
     "mi_op_apply": [vp, vp, vp],
     "mi_op_bytes": [vp, i64p, i64p],

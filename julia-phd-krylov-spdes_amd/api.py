@@ -534,16 +534,26 @@ class AssemblyPlan:
 
 
 class GlobalSchur(Operator):
-    """`x -> apply_global_schur(A_IId, A_IΓd, A_ΓΓ, x; preconds)` (EPDD.jl:596-625), the closure of Example03:101."""
+    """`x -> apply_global_schur(A_IId, A_IΓd, A_ΓΓ, x; preconds)` (EPDD.jl:596-625), the closure of Example03:101.
+    `interior_solvers[d](rhs)` on the host, or — `interior_solvers=None` — the device CG that restates the reference's
+    `IterativeSolvers.cg(A_IId[idom], A_IΓd[idom]*x)` (EPDD.jl:609-619; package default reltol = sqrt(eps))."""
 
-    def __init__(self, ctx: Context, A_IId, A_IΓd, A_ΓΓ, interior_solvers):
+    def __init__(self, ctx: Context, A_IId, A_IΓd, A_ΓΓ, interior_solvers=None, reltol: float = float(np.sqrt(np.finfo(float).eps))):
         ndom = len(A_IΓd)
         n_Γ = A_ΓΓ.shape[0]
         ni = _i64([A.shape[0] for A in A_IId])
         igp, igi, igv = _csc_parts(A_IΓd, 0, ndom)
         (ggp,), (ggi,), (ggv,) = _csc_parts([A_ΓΓ], 0, 1)
-        cb = _wrap_interior(interior_solvers)
         h = vp()
+        if interior_solvers is None:
+            iip, iii, iiv = _csc_parts(A_IId, 0, ndom)
+            check(ctx._L.mi_schur_global_device_create(
+                ctx._h, i64(ndom), i64(n_Γ), ni.ctypes.data_as(i64p), _ptrs(iip, i64p), _ptrs(iii, i64p), _ptrs(iiv, f64p),
+                _ptrs(igp, i64p), _ptrs(igi, i64p), _ptrs(igv, f64p), ggp.ctypes.data_as(i64p), ggi.ctypes.data_as(i64p),
+                ggv.ctypes.data_as(f64p), C.c_double(reltol), C.c_int(0), C.byref(h)))
+            super().__init__(ctx, h)
+            return
+        cb = _wrap_interior(interior_solvers)
         check(ctx._L.mi_schur_global_create(
             ctx._h, i64(ndom), i64(n_Γ), ni.ctypes.data_as(i64p), _ptrs(igp, i64p), _ptrs(igi, i64p), _ptrs(igv, f64p),
             ggp.ctypes.data_as(i64p), ggi.ctypes.data_as(i64p), ggv.ctypes.data_as(f64p), cb, None, C.c_int(0), C.byref(h)))

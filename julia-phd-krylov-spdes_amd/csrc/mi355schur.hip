@@ -418,6 +418,17 @@ int mi_schur_global_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const in
                                        gg_nzval, solve, user, index_base));
 }
 
+int mi_schur_global_device_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, const int64_t *n_i,
+                                  const int64_t *const *ii_colptr, const int64_t *const *ii_rowval,
+                                  const double *const *ii_nzval, const int64_t *const *ig_colptr,
+                                  const int64_t *const *ig_rowval, const double *const *ig_nzval,
+                                  const int64_t *gg_colptr, const int64_t *gg_rowval, const double *gg_nzval,
+                                  double reltol, int index_base, mi_op_t *op) {
+  if (!ii_colptr) return fail(MI_ERR_BAD_ARG, "mi_schur_global_device_create: A_II arrays are NULL");
+  MI_NEW_OP(ctx, op, new GlobalSchurOp(ctx, ndom, n_gamma, n_i, ig_colptr, ig_rowval, ig_nzval, gg_colptr, gg_rowval,
+                                       gg_nzval, nullptr, nullptr, index_base, ii_colptr, ii_rowval, ii_nzval, reltol));
+}
+
 int mi_op_size(mi_op_t op, int64_t *n) {
   if (!op || !op->impl || !n) return fail(MI_ERR_BAD_ARG, "NULL argument");
   *n = op->impl->n;

@@ -761,12 +761,16 @@ struct GlobalSchurOp : Operator {
   DevBuf<double> rhs, sol;
   HostStage stage;
 
+  std::unique_ptr<InteriorCg> icg;  // device interior solve (no callback): IterativeSolvers.cg restated, all subdomains at once
+
   GlobalSchurOp(mi_ctx_s *c, int64_t ndom_, int64_t n_gamma, const int64_t *n_i, const int64_t *const *ig_ptr,
                 const int64_t *const *ig_idx, const double *const *ig_val, const int64_t *gg_ptr, const int64_t *gg_idx,
-                const double *gg_val, mi_interior_solve_fn f, void *u, int base)
+                const double *gg_val, mi_interior_solve_fn f, void *u, int base, const int64_t *const *ii_ptr = nullptr,
+                const int64_t *const *ii_idx = nullptr, const double *const *ii_val = nullptr, double reltol = 0.0)
       : Operator(c, n_gamma), ndom((int)ndom_), solve(f), user(u) {
-    if (!f || ndom_ <= 0 || !n_i || !ig_ptr || !ig_idx || !ig_val || !gg_ptr)
+    if ((!f && !ii_ptr) || ndom_ <= 0 || !n_i || !ig_ptr || !ig_idx || !ig_val || !gg_ptr)
       raise(MI_ERR_BAD_ARG, "mi_schur_global_create: NULL argument");
+    if (ii_ptr && (!ii_idx || !ii_val || !(reltol > 0.0))) raise(MI_ERR_BAD_ARG, "device interior: bad A_II arrays / reltol");
     A_IG.resize(ndom); A_GI.resize(ndom);
     int64_t itot = 0;
     for (int d = 0; d < ndom; ++d) {
@@ -779,19 +783,31 @@ struct GlobalSchurOp : Operator {
     ni_tot = (int)itot;
     A_GG.upload(host_csr(n_gamma, n_gamma, gg_ptr, gg_idx, gg_val, base), c->stream);
     rhs.alloc(ni_tot + 1); sol.alloc(ni_tot + 1);
-    stage.ensure(ni_tot);
+    if (ii_ptr) {
+      HostCsr ii;
+      for (int d = 0; d < ndom; ++d) append_block(ii, host_csr(ni[d], ni[d], ii_ptr[d], ii_idx[d], ii_val[d], base), ioff[d], ni_tot);
+      if (ii.rowptr.empty()) ii.rowptr = {0};
+      icg.reset(new InteriorCg);
+      icg->build(c, ii, ioff, ni, reltol);
+    } else {
+      stage.ensure(ni_tot);
+    }
   }
   bool graph_safe() const override { return false; }
   void apply(const double *x, double *y, const int *) override {
     hipStream_t s = ctx->stream;
     A_GG.launch(0, x, nullptr, y, nullptr, s);  // Sx = A_ΓΓ * x
     for (int d = 0; d < ndom; ++d) A_IG[d].launch(0, x, nullptr, rhs.p + ioff[d], nullptr, s);
-    MI_HIP(hipMemcpyAsync(stage.rhs, rhs.p, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
-    MI_HIP(hipStreamSynchronize(s));
-    for (int d = 0; d < ndom; ++d)
-      if (solve(user, d, ni[d], stage.rhs + ioff[d], stage.sol + ioff[d]) != 0)
-        raise(MI_ERR_CALLBACK, "interior solve callback failed on subdomain %d", d);
-    MI_HIP(hipMemcpyAsync(sol.p, stage.sol, sizeof(double) * ni_tot, hipMemcpyHostToDevice, s));
+    if (icg) {
+      icg->solve(rhs.p, sol.p);
+    } else {
+      MI_HIP(hipMemcpyAsync(stage.rhs, rhs.p, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+      for (int d = 0; d < ndom; ++d)
+        if (solve(user, d, ni[d], stage.rhs + ioff[d], stage.sol + ioff[d]) != 0)
+          raise(MI_ERR_CALLBACK, "interior solve callback failed on subdomain %d", d);
+      MI_HIP(hipMemcpyAsync(sol.p, stage.sol, sizeof(double) * ni_tot, hipMemcpyHostToDevice, s));
+    }
     for (int d = 0; d < ndom; ++d) A_GI[d].launch(1, sol.p + ioff[d], y, y, nullptr, s);  // Sx .-= A_IΓd' * v
   }
   void bytes(int64_t *a, int64_t *dd) const override {

@@ -173,6 +173,14 @@ def test_matrix_free_and_global_schur_vs_oracle(pkg, ctx, orc, fem, ragged):
     Sg = pkg.api.GlobalSchur(ctx, A_IIg, A_IΓg, A_ΓΓ, P.solvers)
     Sgo = orc.apply_global_schur_operator(A_IIg, A_IΓg, A_ΓΓ, P.solvers)
     assert np.array_equal(pkg.api.apply_global_schur(Sg, v), Sgo * v)
+    # the same operator with the interior CG on the device (no callback): against the oracle's restatement of that inexact
+    # solve, at the reference's default reltol = sqrt(eps) and at a tight one
+    for reltol in (float(np.sqrt(np.finfo(float).eps)), 1e-12):
+        Sgd = pkg.api.GlobalSchur(ctx, A_IIg, A_IΓg, A_ΓΓ, None, reltol=reltol)
+        Sgdo = orc.apply_global_schur_operator(A_IIg, A_IΓg, A_ΓΓ, orc.interior_cg_solvers(A_IIg, reltol))
+        yd, yo = Sgd * v, Sgdo * v
+        assert np.abs(yd - yo).max() <= 0.5 * reltol * np.abs(yo).max() + 1e-12 * np.abs(yo).max()
+    assert np.abs(yd - Sgo * v).max() <= 1e-9 * np.abs(yd).max()
     # Example03:175 identity on the device path
     Sa = pkg.api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt)
     assert np.allclose(Sa * v, got, rtol=0, atol=1e-11 * np.abs(got).max())

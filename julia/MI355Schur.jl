@@ -189,6 +189,23 @@ function GlobalSchur(ctx::MiContext, A_IId, A_IΓd, A_ΓΓ::SparseMatrixCSC{Floa
   wrap(ctx, r, (fref, cb))
 end
 
+"""`GlobalSchur(ctx, A_IId, A_IΓd, A_ΓΓ; reltol=sqrt(eps()))`: the same operator with the interior solves on the device
+(`IterativeSolvers.cg(A_IId[idom], A_IΓd[idom]*x)` restated, EPDD.jl:609-619; sqrt(eps) is that package's default)."""
+function GlobalSchur(ctx::MiContext, A_IId, A_IΓd, A_ΓΓ::SparseMatrixCSC{Float64,Int}; reltol=sqrt(eps(Float64)))
+  ndom = length(A_IΓd); ni = Int64[A.n for A in A_IId]
+  iip, iii, iiv = csc_parts(A_IId); igp, igi, igv = csc_parts(A_IΓd)
+  ggp, ggi = Vector{Int64}(A_ΓΓ.colptr), Vector{Int64}(A_ΓΓ.rowval)
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve iip iii iiv igp igi igv ggp ggi begin
+    check(ccall((:mi_schur_global_device_create, lib), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}},
+                 Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Float64, Cint, Ref{Ptr{Cvoid}}),
+                ctx.h, ndom, A_ΓΓ.n, ni, ptrs(iip), ptrs(iii), ptrs(iiv), ptrs(igp), ptrs(igi), ptrs(igv),
+                ggp, ggi, A_ΓΓ.nzval, reltol, 1, r))
+  end
+  wrap(ctx, r)
+end
+
 """A symmetric `SparseMatrixCSC` as a device operator (config 2: `pcg(A, b, x, M)` on the full system)."""
 function MiOperator(ctx::MiContext, A::SparseMatrixCSC{Float64,Int})
   r = Ref{Ptr{Cvoid}}(C_NULL)

@@ -227,7 +227,9 @@ int mi_defpcg(mi_op_t A, mi_op_t M, const double *b, double *x, const double *W,
  *   the concatenation over the operator's subdomains [dom_begin, dom_end) of the arrays passed at create (A_IIdd: its
  *   CSC/CSR values; A_IΓdd: CSC values; A_ΓΓdd); NULL leaves a block unchanged; ii_val needs the device interior solve.
  * mi_schur_matfree_rhs: `get_schur_rhs` (EPDD.jl:835-864): b_schur = b_Γ - Σ_d R_d' A_IΓdd' (A_IIdd \ b_Id) with the
- *   operator's own interior solve; b_I is the concatenation of the b_Id. Collective on a sharded operator. */
+ *   operator's own interior solve; b_I is the concatenation of the b_Id. Collective on a sharded operator. Also accepts
+ *   a global Schur operator (mi_schur_global_*create): the Γ-global form, EPDD.jl:798-821; likewise
+ *   mi_schur_matfree_interior_solutions (there it is the reference's own signature, A_IΓd with global columns). */
 int mi_assembly_plan_create(mi_ctx_t ctx, int64_t nel, int64_t n_node, const int64_t *cells, int index_base,
                             const double *G, const double *area, const double *ue, const double *be, int64_t n_entries,
                             int64_t n_matrix_entries, const int64_t *cptr, const int64_t *ccode, mi_plan_t *plan);

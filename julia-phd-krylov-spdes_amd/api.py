@@ -471,7 +471,7 @@ MatrixFreeLocalSchurs.interior_solutions = _interior_solutions
 
 class LocalSchur(MatrixFreeLocalSchurs):
     """`xd -> apply_local_schur(A_IIdd, A_IΓdd, A_ΓΓdd, xd; precond, reltol)` (EPDD.jl:639-654): ONE subdomain, vectors in
-    its own Γ_d numbering — S_d xd = A_ΓΓdd xd - A_IΓdd' (A_IIdd \ (A_IΓdd xd)). What `assemble_local_schurs` applies to the
+    its own Γ_d numbering — S_d xd = A_ΓΓdd xd - A_IΓdd' A_IIdd^{-1} (A_IΓdd xd). What `assemble_local_schurs` applies to the
     unit vectors (EPDD.jl:667-695) and `prepare_neumann_neumann_schur_precond` wraps (:1152-1189)."""
 
     def __init__(self, ctx: Context, A_IIdd, A_IΓdd, A_ΓΓdd, interior_solver=None, reltol: float = 1e-9):
@@ -558,6 +558,10 @@ class GlobalSchur(Operator):
             ctx._h, i64(ndom), i64(n_Γ), ni.ctypes.data_as(i64p), _ptrs(igp, i64p), _ptrs(igi, i64p), _ptrs(igv, f64p),
             ggp.ctypes.data_as(i64p), ggi.ctypes.data_as(i64p), ggv.ctypes.data_as(f64p), cb, None, C.c_int(0), C.byref(h)))
         super().__init__(ctx, h, keep=(cb, interior_solvers))
+
+
+GlobalSchur.interior_solutions = _interior_solutions      # `get_subdomain_solutions` (EPDD.jl:1014-1025), Γ-global columns
+GlobalSchur.schur_rhs = MatrixFreeLocalSchurs.schur_rhs   # `get_schur_rhs` (EPDD.jl:798-821)
 
 
 # reference-named free functions

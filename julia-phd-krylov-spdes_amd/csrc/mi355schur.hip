@@ -707,17 +707,22 @@ int mi_schur_matfree_set_values(mi_op_t op, const double *ii_val, const double *
     return MI_OK;
   });
 }
+static GlobalSchurOp *as_global(mi_op_t op) {
+  return op && op->impl ? dynamic_cast<GlobalSchurOp *>(op->impl.get()) : nullptr;
+}
 int mi_schur_matfree_rhs(mi_op_t op, const double *b_I, const double *b_gamma, double *b_schur) {
   MatfreeSchurOp *m = as_matfree(op);
-  if (!m || !b_gamma || !b_schur || (m->ni_tot && !b_I))
-    return fail(MI_ERR_BAD_ARG, "mi_schur_matfree_rhs: not a matrix-free local-Schur operator, or NULL argument");
-  mi_ctx_s *c = m->ctx;
+  GlobalSchurOp *gl = as_global(op);
+  const int64_t ni_tot = m ? m->ni_tot : gl ? gl->ni_tot : 0;
+  if ((!m && !gl) || !b_gamma || !b_schur || (ni_tot && !b_I))
+    return fail(MI_ERR_BAD_ARG, "mi_schur_matfree_rhs: not a matrix-free (local or global) Schur operator, or NULL argument");
+  mi_ctx_s *c = op->impl->ctx;
   return guarded([&]() -> int {
     c->use();
     DevBuf<double> s1;
-    In bi(c, b_I, (size_t)m->ni_tot, s1), bg(c, b_gamma, (size_t)m->n, c->scratch_a);
-    InOut out(c, b_schur, (size_t)m->n, c->scratch_b, false);
-    m->schur_rhs(bi.dev, bg.dev, out.dev);
+    In bi(c, b_I, (size_t)ni_tot, s1), bg(c, b_gamma, (size_t)op->impl->n, c->scratch_a);
+    InOut out(c, b_schur, (size_t)op->impl->n, c->scratch_b, false);
+    if (m) m->schur_rhs(bi.dev, bg.dev, out.dev); else gl->schur_rhs(bi.dev, bg.dev, out.dev);
     out.finish();
     MI_HIP(hipStreamSynchronize(c->stream));
     return MI_OK;
@@ -726,15 +731,17 @@ int mi_schur_matfree_rhs(mi_op_t op, const double *b_I, const double *b_gamma, d
 
 int mi_schur_matfree_interior_solutions(mi_op_t op, const double *u_gamma, const double *b_I, double *u_I) {
   MatfreeSchurOp *m = as_matfree(op);
-  if (!m || !u_gamma || (m->ni_tot && (!b_I || !u_I)))
-    return fail(MI_ERR_BAD_ARG, "mi_schur_matfree_interior_solutions: not a matrix-free local-Schur operator, or NULL argument");
-  mi_ctx_s *c = m->ctx;
+  GlobalSchurOp *gl = as_global(op);
+  const int64_t ni_tot = m ? m->ni_tot : gl ? gl->ni_tot : 0;
+  if ((!m && !gl) || !u_gamma || (ni_tot && (!b_I || !u_I)))
+    return fail(MI_ERR_BAD_ARG, "mi_schur_matfree_interior_solutions: not a matrix-free (local or global) Schur operator, or NULL argument");
+  mi_ctx_s *c = op->impl->ctx;
   return guarded([&]() -> int {
     c->use();
     DevBuf<double> s1, s2;
-    In ug(c, u_gamma, (size_t)m->n, c->scratch_a), bi(c, b_I, (size_t)m->ni_tot, s1);
-    InOut out(c, u_I, (size_t)m->ni_tot, s2, false);
-    m->interior_solutions(ug.dev, bi.dev, out.dev);
+    In ug(c, u_gamma, (size_t)op->impl->n, c->scratch_a), bi(c, b_I, (size_t)ni_tot, s1);
+    InOut out(c, u_I, (size_t)ni_tot, s2, false);
+    if (m) m->interior_solutions(ug.dev, bi.dev, out.dev); else gl->interior_solutions(ug.dev, bi.dev, out.dev);
     out.finish();
     MI_HIP(hipStreamSynchronize(c->stream));
     return MI_OK;

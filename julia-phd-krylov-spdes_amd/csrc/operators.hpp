@@ -810,6 +810,30 @@ struct GlobalSchurOp : Operator {
     }
     for (int d = 0; d < ndom; ++d) A_GI[d].launch(1, sol.p + ioff[d], y, y, nullptr, s);  // Sx .-= A_IΓd' * v
   }
+  // A_IId^{-1} v for every subdomain (device pointers; v, out: concatenated over the subdomains)
+  void interior_solve(const double *v, double *out) {
+    hipStream_t s = ctx->stream;
+    if (icg) { icg->solve(v, out); return; }
+    MI_HIP(hipMemcpyAsync(stage.rhs, v, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    for (int d = 0; d < ndom; ++d)
+      if (solve(user, d, ni[d], stage.rhs + ioff[d], stage.sol + ioff[d]) != 0)
+        raise(MI_ERR_CALLBACK, "interior solve callback failed on subdomain %d", d);
+    MI_HIP(hipMemcpyAsync(out, stage.sol, sizeof(double) * ni_tot, hipMemcpyHostToDevice, s));
+  }
+  // b_schur = b_Γ - Σ_d A_IΓd' (A_IId \ b_Id), subdomain by subdomain (get_schur_rhs, EPDD.jl:798-821)
+  void schur_rhs(const double *b_I, const double *b_gamma, double *out) {
+    hipStream_t s = ctx->stream;
+    interior_solve(b_I, sol.p);
+    MI_HIP(hipMemcpyAsync(out, b_gamma, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    for (int d = 0; d < ndom; ++d) A_GI[d].launch(1, sol.p + ioff[d], out, out, nullptr, s);
+  }
+  // u_Id = A_IId \ (b_Id - A_IΓd u_Γ) (get_subdomain_solutions, EPDD.jl:1014-1025)
+  void interior_solutions(const double *u_gamma, const double *b_I, double *u_I) {
+    hipStream_t s = ctx->stream;
+    for (int d = 0; d < ndom; ++d) A_IG[d].launch(1, u_gamma, b_I + ioff[d], rhs.p + ioff[d], nullptr, s);
+    interior_solve(rhs.p, u_I);
+  }
   void bytes(int64_t *a, int64_t *dd) const override {
     int64_t t = A_GG.bytes();
     for (int d = 0; d < ndom; ++d) t += A_IG[d].bytes() + A_GI[d].bytes();

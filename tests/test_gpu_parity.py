@@ -181,6 +181,13 @@ def test_matrix_free_and_global_schur_vs_oracle(pkg, ctx, orc, fem, ragged):
         yd, yo = Sgd * v, Sgdo * v
         assert np.abs(yd - yo).max() <= 0.5 * reltol * np.abs(yo).max() + 1e-12 * np.abs(yo).max()
     assert np.abs(yd - Sgo * v).max() <= 1e-9 * np.abs(yd).max()
+    # get_schur_rhs (EPDD.jl:798-821) and get_subdomain_solutions (:1014-1025) in their Γ-global forms, host callback: exact solves
+    bI = np.concatenate(b_Id)
+    assert np.allclose(Sg.schur_rhs(bI, b_Γ), fem.get_schur_rhs(b_Id, A_IIg, A_IΓg, b_Γ, solvers=P.solvers), rtol=1e-12, atol=1e-14)
+    uI = Sg.interior_solutions(v, bI)
+    ref = np.concatenate(fem.get_subdomain_solutions(v, A_IIg, A_IΓg, b_Id, P.solvers))
+    assert np.allclose(uI, ref, rtol=1e-12, atol=1e-13 * np.abs(ref).max())
+    assert np.linalg.norm(Sgd.interior_solutions(v, bI) - ref) <= 1e-9 * np.linalg.norm(ref)
     # Example03:175 identity on the device path
     Sa = pkg.api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt)
     assert np.allclose(Sa * v, got, rtol=0, atol=1e-11 * np.abs(got).max())

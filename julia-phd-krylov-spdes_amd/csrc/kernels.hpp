@@ -354,7 +354,7 @@ __global__ __launch_bounds__(NT) void k_icg_direction(IcgMeta m, const double *_
 //   NN-apply (SCALE=true) : M_d = ΠS_d, EPDD.jl:1373-1381 (gather r/cnt, `ΠSd[idom]*rd`, result /cnt)
 // Layout: every M_d is stored row-major with its leading dimension padded to a multiple of 16
 // doubles (128 B), so each row is a contiguous, line-aligned stream. A workgroup owns RPW rows per
-// wave (4*RPW rows) described by ONE 32-byte tile record. The first group of matrix loads is issued
+// wave (WAVES*RPW rows, 32 by default) described by ONE 32-byte tile record. The first group of matrix loads is issued
 // before x_d is gathered into LDS (padded with zeros), so the stream is already in flight while
 // the index->x->LDS chain and the barrier complete; after that two groups (2 x 4 x 16 B per lane
 // and row) stay in flight. Each lane multiplies against the LDS copy of x_d and the row sum is
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     }
   }
   // The thread whose column j is also a row of this tile serves that row (at most one column per thread:
-  // the 4*RPW rows are consecutive). Its owner duties need p/r of the node, x[g] and the peer list: load now.
+  // the rows of a tile are consecutive and fewer than the threads). Its owner duties need p/r of the node, x[g] and the peer list: load now.
   int o_q = -1, o_g = 0;
   bool o_own = false;
   double o_a = 0.0, o_x = 0.0;  // PHASE 1: p (next copy), x[g]    PHASE 0: r (next copy)

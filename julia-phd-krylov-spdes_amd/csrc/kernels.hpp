@@ -354,10 +354,11 @@ __global__ __launch_bounds__(NT) void k_icg_direction(IcgMeta m, const double *_
 //   NN-apply (SCALE=true) : M_d = ΠS_d, EPDD.jl:1373-1381 (gather r/cnt, `ΠSd[idom]*rd`, result /cnt)
 // Layout: every M_d is stored row-major with its leading dimension padded to a multiple of 16
 // doubles (128 B), so each row is a contiguous, line-aligned stream. A workgroup owns RPW rows per
-// wave (WAVES*RPW rows, 32 by default) described by ONE 32-byte tile record. The first group of matrix loads is issued
-// before x_d is gathered into LDS (padded with zeros), so the stream is already in flight while
-// the index->x->LDS chain and the barrier complete; after that two groups (2 x 4 x 16 B per lane
-// and row) stay in flight. Each lane multiplies against the LDS copy of x_d and the row sum is
+// wave (WAVES*RPW rows, 32 by default) described by ONE 32-byte tile record. The operand gather
+// (index -> x, two dependent loads) is requested first and the first group of matrix loads right
+// behind it — vector-memory results return in issue order — so the stream is in flight while x_d is
+// staged into LDS (padded with zeros); then one group of 4 x 16 B per lane and row at a time, 16 waves
+// per CU keeping 128 KB in flight. Each lane multiplies against the LDS copy of x_d and the row sum is
 // finished with a wave shuffle tree.
 // Output: row r of subdomain d goes to out_pos[...] = g*W + j, the j-th contribution slot of Γ node
 // g (slots in ascending subdomain order, W = max multiplicity; unused slots stay 0). The

@@ -441,10 +441,24 @@ int mi_op_apply(mi_op_t op, const double *x, double *y) {
     mi_ctx_s *c = op->impl->ctx;
     c->use();
     const size_t n = (size_t)op->impl->n;
-    In xi(c, x, n, op->hx);
-    InOut yo(c, y, n, op->hy, false);
-    op->impl->apply(xi.dev, yo.dev, nullptr);
-    yo.finish();
+    if (c->ptr_mode == MI_PTR_DEVICE) {
+      op->impl->apply(x, y, nullptr);
+      return MI_OK;
+    }
+    // Host pointers (the reference's own Julia loop calling mul! / \ every iteration): through pinned buffers, so both
+    // copies are plain DMA transfers instead of the runtime's staged pageable copies.
+    c->pin_b.ensure(n); c->pin_x.ensure(n);
+    op->hx.ensure(n); op->hy.ensure(n);
+    std::memcpy(c->pin_b.p, x, n * sizeof(double));
+    MI_HIP(hipMemcpyAsync(op->hx.p, c->pin_b.p, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (c->has_comm()) {  // a collective may touch y: keep it in device memory
+      op->impl->apply(op->hx.p, op->hy.p, nullptr);
+      MI_HIP(hipMemcpyAsync(c->pin_x.p, op->hy.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    } else {
+      op->impl->apply(op->hx.p, c->pin_x.p, nullptr);  // the last kernel of the apply writes y straight into pinned memory
+    }
+    MI_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(y, c->pin_x.p, n * sizeof(double));
     return MI_OK;
   });
 }

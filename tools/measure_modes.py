@@ -40,6 +40,14 @@ it, dt = rate(lambda: api.pcg(S, bd, torch.zeros_like(bd), M)[1], 200)
 print(f"pcg device pointers : it={it} {dt * 1e6:8.1f} us/solve {(it - 1) / dt:9.0f} it/s")
 it, dt = rate(lambda: api.pcg(S, b, np.zeros(n), M)[1], 200)
 print(f"pcg host pointers   : it={it} {dt * 1e6:8.1f} us/solve {(it - 1) / dt:9.0f} it/s   (H2D b,x + D2H x per solve)")
+t0 = time.perf_counter()
+for _ in range(300):
+    yh = S * b
+t1 = time.perf_counter()
+for _ in range(300):
+    yd = S * bd
+ctx.synchronize(); t2 = time.perf_counter()
+print(f"S-apply, host pointers (mul! from Julia arrays): {(t1 - t0) / 300 * 1e6:6.1f} us   device pointers: {(t2 - t1) / 300 * 1e6:6.1f} us")
 it, dt = rate(lambda: api.cg(S, bd, torch.zeros_like(bd))[1], 20)
 print(f"cg (no precond)     : it={it} {dt * 1e6:8.1f} us/solve {(it - 1) / dt:9.0f} it/s")
 Sd = np.zeros((n, n))

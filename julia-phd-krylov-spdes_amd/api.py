@@ -377,13 +377,14 @@ def _wrap_interior(solvers: Sequence[Callable]):
     return _lib.INTERIOR_SOLVE_FN(cb)
 
 
-def _csc_parts(mats, lo, hi):
+def _csc_parts(mats, lo, hi, base: int = 0):
+    """CSC arrays of the blocks lo..hi-1 as int64 in the `base` convention (1: what Julia's `colptr`/`rowval` hold)."""
     ptr, idx, val = [], [], []
     for d, m in enumerate(mats):
         if lo <= d < hi:
             m = sp.csc_matrix(m)
             m.sort_indices()
-            ptr.append(_i64(m.indptr)); idx.append(_i64(m.indices)); val.append(_f64(m.data))
+            ptr.append(_i64(m.indptr) + base); idx.append(_i64(m.indices) + base); val.append(_f64(m.data))
         else:
             ptr.append(None); idx.append(None); val.append(None)
     return ptr, idx, val
@@ -396,22 +397,24 @@ class MatrixFreeLocalSchurs(Operator):
     reference's own `IterativeSolvers.cg(A_IIdd, rhs, reltol=reltol)` (EPDD.jl:648-650)."""
 
     def __init__(self, ctx: Context, A_IIdd, A_IΓdd, A_ΓΓdd, ind_Γd_Γ2l, node_Γ_cnt, interior_solvers=None,
-                 reltol: float = 1e-9, dom_slice=None):
+                 reltol: float = 1e-9, dom_slice=None, index_base: int = 0):
+        """`index_base=1`: `ind_Γd_Γ2l` holds 1-based Γ indices and the CSC arrays cross the ABI 1-based, exactly as the
+        Julia shim passes `colptr`/`rowval` (the matrices themselves are scipy objects either way)."""
         ndom = len(A_IΓdd)
         n_Γ = len(node_Γ_cnt)
         lo, hi = _dom_slice(ctx, ndom, dom_slice)
         g = [_i64(a) for a in ind_Γd_Γ2l]
         nd = _i64([a.size for a in g])
         ni = _i64([A.shape[0] for A in A_IIdd])
-        igp, igi, igv = _csc_parts(A_IΓdd, lo, hi)
-        ggp, ggi, ggv = _csc_parts(A_ΓΓdd, lo, hi)
+        igp, igi, igv = _csc_parts(A_IΓdd, lo, hi, index_base)
+        ggp, ggi, ggv = _csc_parts(A_ΓΓdd, lo, hi, index_base)
         h = vp()
         if interior_solvers is None:
-            iip, iii, iiv = _csc_parts(A_IIdd, lo, hi)
+            iip, iii, iiv = _csc_parts(A_IIdd, lo, hi, index_base)
             check(ctx._L.mi_schur_matfree_device_create(
                 ctx._h, i64(ndom), i64(n_Γ), nd.ctypes.data_as(i64p), ni.ctypes.data_as(i64p), _ptrs(g, i64p),
                 _ptrs(iip, i64p), _ptrs(iii, i64p), _ptrs(iiv, f64p), _ptrs(igp, i64p), _ptrs(igi, i64p), _ptrs(igv, f64p),
-                _ptrs(ggp, i64p), _ptrs(ggi, i64p), _ptrs(ggv, f64p), C.c_double(reltol), C.c_int(0), i64(lo), i64(hi),
+                _ptrs(ggp, i64p), _ptrs(ggi, i64p), _ptrs(ggv, f64p), C.c_double(reltol), C.c_int(index_base), i64(lo), i64(hi),
                 C.byref(h)))
             super().__init__(ctx, h)
             return
@@ -419,7 +422,7 @@ class MatrixFreeLocalSchurs(Operator):
         check(ctx._L.mi_schur_matfree_create(
             ctx._h, i64(ndom), i64(n_Γ), nd.ctypes.data_as(i64p), ni.ctypes.data_as(i64p), _ptrs(g, i64p),
             _ptrs(igp, i64p), _ptrs(igi, i64p), _ptrs(igv, f64p), _ptrs(ggp, i64p), _ptrs(ggi, i64p), _ptrs(ggv, f64p),
-            cb, None, C.c_int(0), i64(lo), i64(hi), C.byref(h)))
+            cb, None, C.c_int(index_base), i64(lo), i64(hi), C.byref(h)))
         super().__init__(ctx, h, keep=(cb, interior_solvers))
 
     def set_values(self, ii_val=None, ig_val=None, gg_val=None) -> None:
@@ -474,24 +477,26 @@ class LocalSchur(MatrixFreeLocalSchurs):
     its own Γ_d numbering — S_d xd = A_ΓΓdd xd - A_IΓdd' A_IIdd^{-1} (A_IΓdd xd). What `assemble_local_schurs` applies to the
     unit vectors (EPDD.jl:667-695) and `prepare_neumann_neumann_schur_precond` wraps (:1152-1189)."""
 
-    def __init__(self, ctx: Context, A_IIdd, A_IΓdd, A_ΓΓdd, interior_solver=None, reltol: float = 1e-9):
+    def __init__(self, ctx: Context, A_IIdd, A_IΓdd, A_ΓΓdd, interior_solver=None, reltol: float = 1e-9,
+                 index_base: int = 0):
         n = A_ΓΓdd.shape[0]
-        super().__init__(ctx, [A_IIdd], [A_IΓdd], [A_ΓΓdd], [np.arange(n, dtype=np.int64)], np.ones(n, dtype=np.int64),
-                         None if interior_solver is None else [interior_solver], reltol)
+        super().__init__(ctx, [A_IIdd], [A_IΓdd], [A_ΓΓdd], [np.arange(n, dtype=np.int64) + index_base],
+                         np.ones(n, dtype=np.int64), None if interior_solver is None else [interior_solver], reltol,
+                         index_base=index_base)
 
 
 class AssemblyPlan:
     """Device executor of a `fem.AssemblyPlan` (`mi_plan_t`): `run(a)` is the numeric half of
     `prepare_local_schurs(cells, points, epart, ..., a, f, uexact)` (EPDD.jl:389-546) for a new coefficient vector."""
 
-    def __init__(self, ctx: Context, plan):
+    def __init__(self, ctx: Context, plan, index_base: int = 0):
         self.ctx, self.plan = ctx, plan
         h = vp()
-        cells = _i64(plan.cells)
+        cells = _i64(plan.cells) + index_base      # index_base=1: node numbers as Julia's `cells` holds them
         arrs = [_f64(plan.G), _f64(plan.area), _f64(plan.ue), _f64(plan.be)]
         cptr, ccode = _i64(plan.cptr), _i64(plan.ccode)
         check(ctx._L.mi_assembly_plan_create(
-            ctx._h, i64(cells.shape[1]), i64(plan.n_node), cells.ctypes.data_as(i64p), C.c_int(0),
+            ctx._h, i64(cells.shape[1]), i64(plan.n_node), cells.ctypes.data_as(i64p), C.c_int(index_base),
             *[a.ctypes.data_as(f64p) for a in arrs], i64(plan.n_entries), i64(plan.n_matrix_entries),
             cptr.ctypes.data_as(i64p), ccode.ctypes.data_as(i64p), C.byref(h)))
         self._h = h
@@ -538,25 +543,26 @@ class GlobalSchur(Operator):
     `interior_solvers[d](rhs)` on the host, or — `interior_solvers=None` — the device CG that restates the reference's
     `IterativeSolvers.cg(A_IId[idom], A_IΓd[idom]*x)` (EPDD.jl:609-619; package default reltol = sqrt(eps))."""
 
-    def __init__(self, ctx: Context, A_IId, A_IΓd, A_ΓΓ, interior_solvers=None, reltol: float = float(np.sqrt(np.finfo(float).eps))):
+    def __init__(self, ctx: Context, A_IId, A_IΓd, A_ΓΓ, interior_solvers=None, reltol: float = float(np.sqrt(np.finfo(float).eps)),
+                 index_base: int = 0):
         ndom = len(A_IΓd)
         n_Γ = A_ΓΓ.shape[0]
         ni = _i64([A.shape[0] for A in A_IId])
-        igp, igi, igv = _csc_parts(A_IΓd, 0, ndom)
-        (ggp,), (ggi,), (ggv,) = _csc_parts([A_ΓΓ], 0, 1)
+        igp, igi, igv = _csc_parts(A_IΓd, 0, ndom, index_base)
+        (ggp,), (ggi,), (ggv,) = _csc_parts([A_ΓΓ], 0, 1, index_base)
         h = vp()
         if interior_solvers is None:
-            iip, iii, iiv = _csc_parts(A_IId, 0, ndom)
+            iip, iii, iiv = _csc_parts(A_IId, 0, ndom, index_base)
             check(ctx._L.mi_schur_global_device_create(
                 ctx._h, i64(ndom), i64(n_Γ), ni.ctypes.data_as(i64p), _ptrs(iip, i64p), _ptrs(iii, i64p), _ptrs(iiv, f64p),
                 _ptrs(igp, i64p), _ptrs(igi, i64p), _ptrs(igv, f64p), ggp.ctypes.data_as(i64p), ggi.ctypes.data_as(i64p),
-                ggv.ctypes.data_as(f64p), C.c_double(reltol), C.c_int(0), C.byref(h)))
+                ggv.ctypes.data_as(f64p), C.c_double(reltol), C.c_int(index_base), C.byref(h)))
             super().__init__(ctx, h)
             return
         cb = _wrap_interior(interior_solvers)
         check(ctx._L.mi_schur_global_create(
             ctx._h, i64(ndom), i64(n_Γ), ni.ctypes.data_as(i64p), _ptrs(igp, i64p), _ptrs(igi, i64p), _ptrs(igv, f64p),
-            ggp.ctypes.data_as(i64p), ggi.ctypes.data_as(i64p), ggv.ctypes.data_as(f64p), cb, None, C.c_int(0), C.byref(h)))
+            ggp.ctypes.data_as(i64p), ggi.ctypes.data_as(i64p), ggv.ctypes.data_as(f64p), cb, None, C.c_int(index_base), C.byref(h)))
         super().__init__(ctx, h, keep=(cb, interior_solvers))
 
 
@@ -643,7 +649,11 @@ def _solve(kind: str, A: Operator, M: Optional[Operator], b, x, W, maxit: int, e
         rc = L.mi_eigdefpcg(A._h, M._h, pb, px, pW, i64(nvec), i64(spdim), *tail, pV)
     else:
         raise ValueError(kind)
-    check(rc)
+    try:
+        check(rc)
+    except BoundsError as e:   # the reference mutates x in place before `res_norm[it]` throws: hand the state over
+        e.x, e.it = kx, int(it.value)
+        raise
     k = int(it.value)
     if V is not None:
         return kx, k, res[:k].copy(), V

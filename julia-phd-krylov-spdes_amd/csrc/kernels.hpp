@@ -778,9 +778,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
       st->rTr = rr; st->rTz = rz; st->beta = coef;
       st->it_nxt = it_new;
       if (it_new <= cap) f.res_norm[it_new - 1] = res; else st->overflow = 1;
-      if (stop) st->done = 1;
+      if (stop || it_new > cap) st->done = 1;
     }
-    if (stop) return;  // same decision in every workgroup
+    if (stop || it_new > cap) return;  // same decision in every workgroup (it_new > cap: the reference's BoundsError)
   }
 
   // ---- operand of this GEMV into LDS; rows of this tile: value for the epilogue dot, owners' stores
@@ -790,8 +790,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     if (j < t.ld) {
       double v = 0.0, vs = 0.0;
       if (j < n) {
-        v = PHASE == 1 ? cv[q] + (-coef) * cs[q]          // r - alpha*Ap
-                       : coef * cv[q] + cs[q];            // beta*p + z
+        // (the first launch of a solve takes r_0 as it is: the contribution rows still hold the previous solve's
+        // values, and 0 * NaN left there by a solve that ended non-finite would poison every later solve)
+        v = PHASE == 1 ? (first1 ? cv[q] : cv[q] + (-coef) * cs[q])   // r - alpha*Ap
+                       : coef * cv[q] + cs[q];                        // beta*p + z
         vs = PHASE == 1 ? v / cc[q] : v;
       }
       xs[j] = vs;
@@ -1043,8 +1045,9 @@ __global__ __launch_bounds__(NT) void k_update_p(int n, SolverState *st, const d
     const long long it = st->it + 1;
     st->it = it;
     const double res = sqrt(rr);
-    if (it <= st->res_cap) res_norm[it - 1] = res; else st->overflow = 1;
-    st->done = !((it < st->maxit) && (res > st->tol));
+    const bool over = it > st->res_cap;  // the reference's `res_norm[it] = ...` throws BoundsError here: stop
+    if (!over) res_norm[it - 1] = res; else st->overflow = 1;
+    st->done = over || !((it < st->maxit) && (res > st->tol));
   }
 }
 // Entry and exit of a solve, one launch each instead of a handful of small copies (each a separate blit on the stream):
@@ -1248,7 +1251,7 @@ __global__ __launch_bounds__(NTF) void k_fused_p(int n, SolverState *st, AsmView
     st->it = it;
     const double res = sqrt(rr);
     if (it <= cap) res_norm[it - 1] = res; else st->overflow = 1;
-    st->done = !((it < maxit) && (res > tol));
+    st->done = it > cap || !((it < maxit) && (res > tol));  // it > cap: BoundsError in the reference, the loop ends there
   }
 }
 // Unpreconditioned cg (cg.jl:35-47): both halves of the iteration in ONE single-workgroup launch — z is r,
@@ -1300,7 +1303,7 @@ __global__ __launch_bounds__(NTF) void k_fused_cg(int n, SolverState *st, AsmVie
     st->it = it;
     const double res = sqrt(rr);
     if (it <= cap) res_norm[it - 1] = res; else st->overflow = 1;
-    st->done = !((it < maxit) && (res > tol));
+    st->done = it > cap || !((it < maxit) && (res > tol));  // it > cap: BoundsError in the reference, the loop ends there
   }
 }
 

@@ -344,7 +344,7 @@ int mi_ctx_allreduce_sum(mi_ctx_t ctx, double *buf, int64_t n) {
   return guarded([&]() -> int {
     ctx->use();
     InOut v(ctx, buf, (size_t)n, ctx->scratch_a, true);
-    if (ctx->comm) MI_NCCL(Rccl::get().AllReduce(v.dev, v.dev, (size_t)n, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    ctx->allreduce(v.dev, (size_t)n);  // RCCL or the in-process loopback group; a no-op without a communicator
     v.finish();
     return MI_OK;
   });
@@ -451,7 +451,7 @@ int mi_op_apply(mi_op_t op, const double *x, double *y) {
     op->hx.ensure(n); op->hy.ensure(n);
     std::memcpy(c->pin_b.p, x, n * sizeof(double));
     MI_HIP(hipMemcpyAsync(op->hx.p, c->pin_b.p, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (c->has_comm()) {  // a collective may touch y: keep it in device memory
+    if (c->has_comm() || !op->impl->writes_y_once()) {  // a collective or read-modify-write kernels touch y: keep it in device memory
       op->impl->apply(op->hx.p, op->hy.p, nullptr);
       MI_HIP(hipMemcpyAsync(c->pin_x.p, op->hy.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     } else {

@@ -57,6 +57,8 @@ struct Operator {
   virtual int diag_kind(const double **dinv) const { return 0; }
   virtual DenseBlockOp *as_dense() { return nullptr; }
   virtual bool graph_safe() const { return true; }  // false: apply synchronises with the host
+  // true: y is written exactly once, by the last kernel of apply(), and never read — it may then be pinned host memory
+  virtual bool writes_y_once() const { return true; }
   virtual void bytes(int64_t *apply_b, int64_t *dominant_b) const = 0;
   virtual void apply_dominant(const double *x) = 0;
 };
@@ -794,6 +796,7 @@ struct GlobalSchurOp : Operator {
     }
   }
   bool graph_safe() const override { return false; }
+  bool writes_y_once() const override { return false; }  // y = A_ΓΓ x, then ndom in-place `y -= A_IΓd' v` passes
   void apply(const double *x, double *y, const int *) override {
     hipStream_t s = ctx->stream;
     A_GG.launch(0, x, nullptr, y, nullptr, s);  // Sx = A_ΓΓ * x

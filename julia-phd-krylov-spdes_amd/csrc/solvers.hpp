@@ -400,8 +400,11 @@ struct Krylov {
   void begin(const double *b_in, const double *x_in, const double *W_in, int64_t &maxit, double &eps, int64_t &cap_dev) {
     if (eps <= 0.0) eps = 1e-7;           // RecyclingKrylovSolvers.jl:21
     if (maxit == 0) maxit = n;            // cg.jl:25
-    cap_dev = std::min<int64_t>(maxit, (int64_t)n) + 1;  // reference: res_norm has n entries
-    if ((size_t)cap_dev > ws.res_norm.n) { ws.drop_graphs(); ws.res_norm.alloc((size_t)cap_dev); }
+    // reference: res_norm has n entries and `res_norm[it] = ...` throws BoundsError at it = n + 1 (cg.jl:23,47), which
+    // only maxit > n can reach: the device loop stops there too (overflow flag -> MI_ERR_RES_CAPACITY), with x updated
+    // exactly as often as the reference had updated it when it threw
+    cap_dev = std::max<int64_t>(1, std::min<int64_t>(maxit, (int64_t)n));
+    if ((size_t)cap_dev + 1 > ws.res_norm.n) { ws.drop_graphs(); ws.res_norm.alloc((size_t)cap_dev + 1); }
     if (nvec > 0) ws.ensure_deflation(nvec);
     const size_t vb = sizeof(double) * (size_t)n;
     hipLaunchKernelGGL(k_solve_begin, dim3(g), dim3(NT), 0, s, n, b_in, x_in, ws.b, ws.x, ws.st, eps, (long long)maxit,

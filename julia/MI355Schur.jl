@@ -2,22 +2,35 @@
 #
 # Drop this module next to Fem/ and RecyclingKrylovSolvers/ of venkovic/julia-phd-krylov-spdes and
 # `push!(LOAD_PATH, "./MI355Schur/")`. It is purely mechanical: every function is one `ccall`.
-# It exports the reference's own names for the hot path, so Example03/07-style scripts change only
-# the lines that BUILD the operators (see INTEGRATION.md); `pcg`/`defpcg` calls stay as they are.
 #
-# NOTE: there is no `julia` in the build container, so this file has been reviewed, not executed.
+# It EXTENDS the reference's own generic functions with methods on `MiOperator` and never defines a second
+# function of the same name: `cg`, `pcg`, `defcg`, `defpcg`, `eigcg`, … are imported from RecyclingKrylovSolvers
+# (exports at RecyclingKrylovSolvers.jl:10-13) and `apply_local_schurs`, `apply_global_schur`,
+# `apply_neumann_neumann_schur`, `get_schur_rhs`, `get_subdomain_solutions`, `NeumannNeumannSchurPreconditioner`
+# from Fem (exports at Fem/Fem.jl:54-75). A script that does `using Fem; using RecyclingKrylovSolvers; using MI355Schur`
+# (Example03:6-7 plus one line) therefore keeps every unqualified call site — `pcg(S, b, x, Πnn)` (Example03:193),
+# `defpcg(S, b, x, ϕ, Πnn)` (:214, :224) — and Julia's dispatch picks the device method when `S` is a `MiOperator`.
+# Only names the reference does not have are exported from here.
+#
+# NOTE: there is no `julia` in the build container, so this file has been reviewed, not executed;
+# tests/test_julia_shim_cpu.py checks it mechanically (no shadowed export, every `ccall` signature against
+# include/mi355schur.h, `index_base = 1` at every create).
 module MI355Schur
 
 using LinearAlgebra
 using SparseArrays: SparseMatrixCSC
 import Base: *, \, size
 import LinearAlgebra: mul!, ldiv!
+import RecyclingKrylovSolvers
+import RecyclingKrylovSolvers: cg, pcg, defcg, defpcg, eigcg, eigpcg, eigdefcg, eigdefpcg, initcg, initpcg
+import Fem
+import Fem: apply_local_schur, apply_local_schurs, apply_global_schur, apply_neumann_neumann_schur,
+            get_schur_rhs, get_subdomain_solutions, NeumannNeumannSchurPreconditioner
 
+# new names only (none of them is exported by Fem or RecyclingKrylovSolvers)
 export MiContext, MiOperator, MiPrecond,
-       LocalSchurs, MatrixFreeLocalSchurs, GlobalSchur, NeumannNeumannSchurPreconditioner,
-       apply_local_schurs, apply_global_schur, apply_neumann_neumann_schur,
-       AssemblyPlan, assemble!, set_values!, get_schur_rhs,
-       cg, pcg, defcg, defpcg, eigcg, eigpcg, eigdefcg, eigdefpcg, initcg, initpcg
+       LocalSchurs, LocalSchur, MatrixFreeLocalSchurs, GlobalSchur,
+       AssemblyPlan, assemble!, set_values!
 
 const lib = get(ENV, "MI355SCHUR_LIB", "libmi355schur")
 const MI_ERR_SINGULAR = Cint(-3)
@@ -99,7 +112,9 @@ function LocalSchurs(ctx::MiContext, Sd::Vector, ind_Γd_Γ2l::Vector{Dict{Int,I
   wrap(ctx, r)
 end
 
-"""`NeumannNeumannSchurPreconditioner(ctx, ΠSd, ind_Γd_Γ2l, node_Γ_cnt)` (EPDD.jl:1111-1137)."""
+"""`NeumannNeumannSchurPreconditioner(ctx, ΠSd, ind_Γd_Γ2l, node_Γ_cnt)`: a method added to the constructor of Fem's
+own struct (EPDD.jl:1111-1137; its fields are `ΠSd`, `ind_Γd_Γ2l`, `node_Γ_cnt`): with a `MiContext` in front the blocks
+go to the device and a `MiOperator` comes back, usable wherever the reference uses `Πnn \\ r` / `ldiv!` (:1389-1403)."""
 function NeumannNeumannSchurPreconditioner(ctx::MiContext, ΠSd::Vector{Matrix{Float64}},
                                            ind_Γd_Γ2l::Vector{Dict{Int,Int}}, node_Γ_cnt::Vector{Int};
                                            dom_range=(0, length(ΠSd)))
@@ -216,7 +231,23 @@ function MiOperator(ctx::MiContext, A::SparseMatrixCSC{Float64,Int})
   wrap(ctx, r)
 end
 
-# reference-named free functions (EPDD.jl:711, 761, 596, 1361)
+"""`MiOperator(ctx, Πnn::NeumannNeumannSchurPreconditioner)`: the reference's own preconditioner object — what
+`prepare_neumann_neumann_schur_precond(Sd_local_mat, ind_Γd_Γ2l, node_Γ_cnt)` returns (EPDD.jl:1201-1220; Example03:139,
+Example07:152-154) — copied to the device as it is."""
+MiOperator(ctx::MiContext, Πnn::NeumannNeumannSchurPreconditioner) =
+  NeumannNeumannSchurPreconditioner(ctx, Πnn.ΠSd, Πnn.ind_Γd_Γ2l, Πnn.node_Γ_cnt)
+
+"""`LocalSchur(ctx, A_IIdd, A_IΓdd, A_ΓΓdd; reltol=1e-9)`: ONE subdomain, `xd -> apply_local_schur(A_IIdd, A_IΓdd,
+A_ΓΓdd, xd; reltol)` (EPDD.jl:639-654) in its own Γ_d numbering, interior solve on the device."""
+function LocalSchur(ctx::MiContext, A_IIdd::SparseMatrixCSC{Float64,Int}, A_IΓdd::SparseMatrixCSC{Float64,Int},
+                    A_ΓΓdd::SparseMatrixCSC{Float64,Int}; reltol=1e-9)
+  n = A_ΓΓdd.n
+  MatrixFreeLocalSchurs(ctx, [A_IIdd], [A_IΓdd], [A_ΓΓdd], [Dict{Int,Int}(i => i for i in 1:n)], ones(Int, n); reltol=reltol)
+end
+
+# Methods added to the reference's own functions (EPDD.jl:639, 711, 761, 596, 1361): the operator handle takes the
+# place of the block arrays, the vector argument stays last.
+apply_local_schur(S::MiOperator, xd::Vector{Float64}) = S * xd
 apply_local_schurs(S::MiOperator, x::Vector{Float64}) = S * x
 apply_global_schur(S::MiOperator, x::Vector{Float64}) = S * x
 apply_neumann_neumann_schur(Πnn::MiOperator, r::Vector{Float64}) = Πnn * r
@@ -277,6 +308,17 @@ set_values!(S::MiOperator, ii, ig, gg) =
 function get_schur_rhs(S::MiOperator, b_I::Vector{Float64}, b_Γ::Vector{Float64})      # EPDD.jl:835-864
   out = similar(b_Γ)
   check(ccall((:mi_schur_matfree_rhs, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), S.h, b_I, b_Γ, out)); out
+end
+# the reference's own container: b_Id::Vector{Vector{Float64}} (one vector per subdomain), concatenated for the library
+get_schur_rhs(S::MiOperator, b_Id::Vector{Vector{Float64}}, b_Γ::Vector{Float64}) = get_schur_rhs(S, reduce(vcat, b_Id), b_Γ)
+"""`get_subdomain_solutions(S, u_Γ, b_Id)` (EPDD.jl:1014-1025): `u_Id = A_IId \\ (b_Id - A_IΓd u_Γ)` with the operator's
+own interior solve; returns one vector per subdomain like the reference."""
+function get_subdomain_solutions(S::MiOperator, u_Γ::Vector{Float64}, b_Id::Vector{Vector{Float64}})
+  b_I = reduce(vcat, b_Id); u_I = similar(b_I)
+  check(ccall((:mi_schur_matfree_interior_solutions, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+              S.h, u_Γ, b_I, u_I))
+  ends = cumsum(length.(b_Id))
+  [u_I[(e - length(b) + 1):e] for (e, b) in zip(ends, b_Id)]
 end
 
 # eigCG family and Init-CG (eigcg.jl:27-33, 143-150; defcg.jl:111-116, 337-343; initcg.jl:28-33, 106-111).

@@ -360,6 +360,7 @@ int orc_lu_solve(i64 n, const double *A, double *b) {
 
 /* ------------------------------------------------------------------ solvers */
 #define ORC_EPS_DEFAULT 1e-7 /* RecyclingKrylovSolvers.jl:21 */
+#define ORC_BOUNDS INT64_MIN   /* returned where the reference throws BoundsError on res_norm[n + 1]; x is as the reference left it */
 
 /* cg (cg.jl:14-50). res_norm must hold n entries (cg.jl:23). Returns it. */
 i64 orc_cg(const orc_op *A, const double *b, double *x, i64 maxit, double eps, double *res_norm) {
@@ -368,6 +369,7 @@ i64 orc_cg(const orc_op *A, const double *b, double *x, i64 maxit, double eps, d
   double *p = r + n, *Ap = p + n;
   if (maxit == 0) maxit = n;
   i64 it = 1;
+  int bounds = 0;
   orc_op_apply(A, x, Ap);
   for (i64 i = 0; i < n; ++i) r[i] = b[i] - Ap[i];
   double rTr = orc_dot(n, r, r);
@@ -385,10 +387,11 @@ i64 orc_cg(const orc_op *A, const double *b, double *x, i64 maxit, double eps, d
     beta *= rTr;
     orc_axpby(n, 1.0, r, beta, p);
     it += 1;
+    if (it > n) { bounds = 1; break; } /* res_norm has n entries: `res_norm[it] = ...` throws BoundsError (maxit > n only) */
     res_norm[it - 1] = sqrt(rTr);
   }
   free(r);
-  return it;
+  return bounds ? ORC_BOUNDS : it;
 }
 
 /* pcg (cg.jl:67-109). */
@@ -399,6 +402,7 @@ i64 orc_pcg(const orc_op *A, const orc_op *M, const double *b, double *x, i64 ma
   double *z = r + n, *p = z + n, *Ap = p + n;
   if (maxit == 0) maxit = n;
   i64 it = 1;
+  int bounds = 0;
   orc_op_apply(A, x, Ap);
   for (i64 i = 0; i < n; ++i) r[i] = b[i] - Ap[i];
   double rTr = orc_dot(n, r, r);
@@ -420,10 +424,11 @@ i64 orc_pcg(const orc_op *A, const orc_op *M, const double *b, double *x, i64 ma
     beta *= rTz;
     orc_axpby(n, 1.0, z, beta, p);
     it += 1;
+    if (it > n) { bounds = 1; break; } /* res_norm has n entries: `res_norm[it] = ...` throws BoundsError (maxit > n only) */
     res_norm[it - 1] = sqrt(rTr);
   }
   free(r);
-  return it;
+  return bounds ? ORC_BOUNDS : it;
 }
 
 /* Shared deflation set-up (defcg.jl:41-54 / 261-275): WtA rows = A*W[:,i] (the FunctionMap branch;
@@ -480,6 +485,7 @@ i64 orc_defcg(const orc_op *A, const double *b, double *x, const double *W, i64 
   if (info) { free(buf); return -(i64)info; }
   if (maxit == 0) maxit = n;
   i64 it = 1;
+  int bounds = 0;
   orc_op_apply(A, x, Ap);
   for (i64 i = 0; i < n; ++i) r[i] = b[i] - Ap[i];
   double rTr = orc_dot(n, r, r);
@@ -501,10 +507,11 @@ i64 orc_defcg(const orc_op *A, const double *b, double *x, const double *W, i64 
     if (info) { free(buf); return -(i64)info; }
     for (i64 i = 0; i < n; ++i) p[i] = (beta * p[i] + r[i]) - Wmu[i];
     it += 1;
+    if (it > n) { bounds = 1; break; } /* res_norm has n entries: `res_norm[it] = ...` throws BoundsError (maxit > n only) */
     res_norm[it - 1] = sqrt(rTr);
   }
   free(buf);
-  return it;
+  return bounds ? ORC_BOUNDS : it;
 }
 
 /* defpcg (defcg.jl:242-308), argument order (A,b,x,W,M). */
@@ -518,6 +525,7 @@ i64 orc_defpcg(const orc_op *A, const orc_op *M, const double *b, double *x, con
   if (info) { free(buf); return -(i64)info; }
   if (maxit == 0) maxit = n;
   i64 it = 1;
+  int bounds = 0;
   orc_op_apply(A, x, Ap);
   for (i64 i = 0; i < n; ++i) r[i] = b[i] - Ap[i];
   double rTr = orc_dot(n, r, r);
@@ -543,10 +551,11 @@ i64 orc_defpcg(const orc_op *A, const orc_op *M, const double *b, double *x, con
     if (info) { free(buf); return -(i64)info; }
     for (i64 i = 0; i < n; ++i) p[i] = (beta * p[i] + z[i]) - Wmu[i];
     it += 1;
+    if (it > n) { bounds = 1; break; } /* res_norm has n entries: `res_norm[it] = ...` throws BoundsError (maxit > n only) */
     res_norm[it - 1] = sqrt(rTr);
   }
   free(buf);
-  return it;
+  return bounds ? ORC_BOUNDS : it;
 }
 
 int orc_set_threads(int nt) {

@@ -211,6 +211,10 @@ def _solve(fn, A, M, b, x, W, maxit, eps):
         args += [_p(W, f64p), C.c_int64(W.shape[1])]
     args += [C.c_int64(maxit), C.c_double(eps), _p(res, f64p)]
     it = int(fn(*args))
+    if it == -2 ** 63:
+        err = BoundsError(f"res_norm[{n + 1}]: the reference's res_norm has n = {n} entries (cg.jl:23,47; maxit > n only)")
+        err.x = x          # the caller's x as the reference had mutated it when it threw
+        raise err
     if it < 0:
         raise SingularException(-it)
     return x, it, res[:it].copy()

@@ -86,3 +86,18 @@ def test_shard_domains_covers_all_subdomains(pkg):
             assert parts[0][0] == 0 and parts[-1][1] == ndom
             assert all(parts[i][1] == parts[i + 1][0] for i in range(nr - 1))
     assert [pkg.api.shard_domains(8, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 8)]
+
+
+def test_plain_c_driver_compiles_against_the_header(pkg, tmp_path):
+    """tests/c/abi_drive.c (run by the gpu suite) must compile as C11 with -Werror against include/mi355schur.h and link
+    against the library: the header is then a valid C header, not only something ctypes mirrors."""
+    import subprocess
+    import __graft_entry__ as graft
+    graft.build()
+    lib_dir = os.path.dirname(pkg._lib.LIB_PATH)
+    exe = str(tmp_path / "abi_drive")
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_drive.c"), "-o", exe, "-L", lib_dir, "-lmi355schur", "-lm",
+                           f"-Wl,-rpath,{lib_dir}"])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr       # no GPU work without arguments

@@ -119,6 +119,82 @@ def bench_full_system(args):
     OUT.emit(json.dumps(out))
 
 
+def secondary_measurements(args, api, fem, ctx, S, M, b_dev, n_Γ, ndom, bytes_iter, e0, e1):
+    """The other loops of the path on the SAME device-resident operators, each timed like the headline (complete solves
+    from x0 = 0, HIP events on the library's stream, median): `defpcg(S, b, 0, W, ΠSnn)` with the nvec = ndom + 10
+    least-dominant eigenvectors of S (Example03:206-214), the recycling pair `eigpcg -> eigdefpcg` with nvec = 1.25 ndom,
+    spdim = 3 ndom (Example09:39-40, _Functions.jl:345,364), unpreconditioned `cg(S, b, 0)`; and config 2. Each entry:
+    loop iterations/s, time per loop iteration (difference of full and maxit-capped solves) and that iteration's HBM
+    roofline fraction = algorithmic bytes of one iteration / time / 8 TB/s."""
+    import torch
+    out = {}
+    t_all = time.perf_counter()
+
+    def timed(solve, reps=12):
+        ts, last = [], None
+        for k in range(reps + 2):
+            torch.cuda.synchronize()
+            e0.record()
+            last = solve()
+            e1.record()
+            if k >= 2:
+                ts.append(e0.elapsed_ms(e1))
+        return float(np.median(ts)), last
+
+    def entry(name, solve_full, solve_short, short_it, bytes_per_iter, extra=None):
+        t_full, r = timed(solve_full)
+        it = r[1]
+        e = {"it": it, "iterations_per_s": round((it - 1) / (t_full * 1e-3), 1), "ms_per_solve": round(t_full, 4)}
+        if it > short_it + 2:
+            t_short, _ = timed(solve_short)
+            us_it = (t_full - t_short) * 1e3 / (it - short_it)
+            e.update({"us_per_iteration": round(us_it, 2), "bytes_per_iteration": int(bytes_per_iter),
+                      "roofline_frac_iteration": round(bytes_per_iter / (us_it * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
+        if extra:
+            e.update(extra)
+        out[name] = e
+
+    z = lambda: torch.zeros(n_Γ, dtype=torch.float64, device="cuda")   # noqa: E731
+    # W: least-dominant eigenvectors of the assembled S (dense eigh on the device stands in for KrylovKit, Example03:209)
+    eye = torch.eye(n_Γ, dtype=torch.float64, device="cuda")
+    Sd = torch.stack([S.apply(eye[k].contiguous()) for k in range(n_Γ)], dim=1)
+    ctx.synchronize()
+    nvec_def = ndom + 10
+    W = torch.linalg.eigh((Sd + Sd.T) / 2)[1][:, :nvec_def].T.contiguous().T      # n x nvec, column-major
+    del Sd, eye
+    vec_bytes = lambda nv: 2 * nv * n_Γ * 8                                       # noqa: E731  WtA*z and W*mu streams
+    entry(f"defpcg_nvec{nvec_def}", lambda: api.defpcg(S, b_dev, z(), W, M, eps=args.eps),
+          lambda: api.defpcg(S, b_dev, z(), W, M, maxit=3, eps=args.eps), 3, bytes_iter + vec_bytes(nvec_def))
+    nvec, spdim = int(1.25 * ndom), 3 * ndom
+    entry(f"eigpcg_nvec{nvec}_spdim{spdim}", lambda: api.eigpcg(S, b_dev, z(), M, nvec, spdim, eps=args.eps),
+          lambda: api.eigpcg(S, b_dev, z(), M, nvec, spdim, maxit=3, eps=args.eps), 3, bytes_iter)
+    Wrec = api.eigpcg(S, b_dev, z(), M, nvec, spdim, eps=args.eps)[3]
+    entry(f"eigdefpcg_nvec{nvec}_spdim{spdim}", lambda: api.eigdefpcg(S, b_dev, z(), M, Wrec, spdim, eps=args.eps),
+          lambda: api.eigdefpcg(S, b_dev, z(), M, Wrec, spdim, maxit=3, eps=args.eps), 3, bytes_iter + vec_bytes(nvec) * 2)
+    entry("cg_unpreconditioned", lambda: api.cg(S, b_dev, z(), eps=args.eps),
+          lambda: api.cg(S, b_dev, z(), maxit=20, eps=args.eps), 20, bytes_iter // 2)
+    # ---- config 2: N = 500, full A, Jacobi-PCG (Example01:33-61 with Jacobi for AMG)
+    mesh = fem.get_mesh(500)
+    d = fem.get_dirichlet_inds(mesh.points, mesh.point_marker)
+    A, b = fem.do_isotropic_elliptic_assembly(mesh.cells, mesh.points, d, mesh.point_marker,
+                                              lambda x, y: 0.1 + 0.0001 * x * y, lambda x, y: -1.0 + 0 * x,
+                                              lambda x, y: 3.0 + 0 * x)
+    n = b.size
+    Aop, Mj = api.SparseMatrixCSC(ctx, A), api.JacobiPreconditioner(ctx, A.diagonal())
+    bd = torch.from_numpy(b).cuda()
+    zf = lambda: torch.zeros(n, dtype=torch.float64, device="cuda")             # noqa: E731
+    _, spmv_bytes = Aop.bytes()
+    Aop.apply_dominant(bd, reps=20); ctx.synchronize()
+    us = kernel_us(api, ctx, Aop, bd, 200)
+    entry("config2_fullA_jacobi_pcg_250k", lambda: api.pcg(Aop, bd, zf(), Mj, eps=args.eps),
+          lambda: api.pcg(Aop, bd, zf(), Mj, maxit=100, eps=args.eps), 100, spmv_bytes + 120 * n,
+          {"workload": f"configs[1]: N=500, n={n}, nnz={A.nnz}, pcg(A,b,0,Jacobi)",
+           "spmv_replayed_us": round(us, 3), "spmv_bytes": int(spmv_bytes),
+           "spmv_replayed_frac": round(spmv_bytes / us / 1e3 / HBM_PEAK_GBS, 4)})
+    out["wall_s"] = round(time.perf_counter() - t_all, 1)
+    return out
+
+
 class StdoutToStderr:
     """Everything written to fd 1 while this is active goes to stderr (RCCL prints a version banner on stdout when a
     communicator is created); `emit` writes one line to the real stdout — the ONE JSON line of the contract."""
@@ -134,6 +210,39 @@ class StdoutToStderr:
 
 
 OUT = None
+
+
+def spawn_ranks(n: int) -> None:
+    """Run this same command line as n rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set the way
+    torch.distributed.run sets them) and wait for them. Rank 0 prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=OUT._saved))   # the real stdout (this process's fd 1 points at stderr by now)
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        raise SystemExit(f"rank exit codes {codes}")
+
+
+def launcher_selftest(rank: int, world: int) -> None:
+    """--launcher-selftest: what the spawned ranks do instead of the benchmark — a gloo rendezvous and one all-reduce
+    on the CPU (tests/test_multirank_cpu.py checks the launcher with it; no GPU involved)."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    assert dist.get_rank() == rank and dist.get_world_size() == world
+    if rank == 0:
+        OUT.emit(json.dumps({"launcher": "ok", "n_gpus": world, "sum": t.item(), "master": os.environ["MASTER_ADDR"]}))
+    dist.destroy_process_group()
 
 
 def main():
@@ -157,13 +266,21 @@ def main():
     ap.add_argument("--workload", choices=["schur", "fullA"], default="schur",
                     help="schur: configs[2] (headline, default). fullA: configs[1], pcg on the full matrix (CSR SpMV + BLAS-1)")
     ap.add_argument("--eps", type=float, default=1e-7, help="stop tolerance (reference constant 1e-7; other values for analysis only)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (deflated / recycling loops, config 2)")
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as fresh children, BEFORE this
+        # process touches the GPU (it never does: it only waits), one rank per GPU, rendezvous on 127.0.0.1
+        return spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.launcher_selftest:
+        return launcher_selftest(rank, world)
 
     if args.workload == "fullA":
         return bench_full_system(args)
@@ -319,9 +436,16 @@ def main():
     achieved = bytes_launch / (k_us * 1e-6) / 1e9
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "bytes_per_launch": int(bytes_launch), "us_per_launch": round(k_us, 3),
+                "traffic": traffic, "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_pass.sh); not re-measured in this run",
+                "bytes_per_launch": int(bytes_launch), "us_per_launch": round(k_us, 3),
                 "plain_gemv": {"S_apply_us": round(k_ms * 1e3, 3), "S_apply_GBs": round(bytes_dom / (k_ms * 1e-3) / 1e9, 1),
                                "NN_apply_us": round(nn_ms * 1e3, 3), "NN_apply_GBs": round(bytes_nn / (nn_ms * 1e-3) / 1e9, 1)}}
+
+    # ---------------- secondary workloads, measured in the same run (rank 0, N=1): the deflated / recycling loops of
+    # config 5 on the same 1M-DoF operators, and config 2 (full-A Jacobi-PCG at 250k DoF)
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        secondary = secondary_measurements(args, api, fem, ctx, S, M, b_dev, n_Γ, ndom, bytes_dom + bytes_nn, e0, e1)
 
     # ---------------- CPU baseline: the oracle (C restatement) on this box's host cores, rank 0, N=1 only
     cpu = None
@@ -362,6 +486,7 @@ def main():
                        "final_relres": relres, "launches_per_iteration": 2 if folded else 4},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "secondary": secondary,
         }
         OUT.emit(json.dumps(out))
     if multi:

@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(NT) void k_solve_begin(int n, const double *__restr
   }
   // x0_zero was left at 1 by the previous solve's k_solve_end (0 after allocation): it survives only if every entry is 0
   if (__syncthreads_or(nz) && threadIdx.x == 0) st->x0_zero = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { st->eps = eps; st->maxit = maxit; st->res_cap = res_cap; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st->eps = eps; st->maxit = maxit; st->res_cap = res_cap; st->done = 0; }
 }
 // out: x -> caller's vector (device), `it` / done / overflow and the first min(it, ncap) residual norms -> pinned host memory.
 __global__ __launch_bounds__(NT) void k_solve_end(int n, const SolverState *st, int fold, const double *__restrict__ x,

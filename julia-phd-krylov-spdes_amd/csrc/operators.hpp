@@ -323,6 +323,8 @@ struct DenseBlockOp : Operator {
   double *fold_part0(bool reduced = false) const { return (reduced ? fold_pack_all.p : fold_pack.p) + fold_con_n; }
   void reduce_fold() { ctx->allreduce(fold_pack.p, fold_pack_all.p, fold_pack_n); }
   DevBuf<GemvTile> tiles;
+  std::vector<long long> moff_h;  // per local subdomain: element offset of its block in M (row-major, ld_h[dl])
+  std::vector<int> ld_h;
   int64_t alg_bytes = 0;
   DenseMeta meta{};
 
@@ -384,6 +386,7 @@ struct DenseBlockOp : Operator {
       }
     }
     ntiles = (int)tv.size();
+    moff_h = moff; ld_h = ldv;
     M.alloc((size_t)tot);
     // column-major (Julia) -> padded row-major, one block at a time
     for (int dl = 0; dl < maps.ndl; ++dl) {

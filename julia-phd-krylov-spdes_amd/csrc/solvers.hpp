@@ -18,6 +18,7 @@
 
 #include "eig_kernels.hpp"
 #include "operators.hpp"
+#include "resident.hpp"
 
 namespace mi {
 
@@ -30,6 +31,91 @@ struct GraphKey {
   int tag = 0;      // 4*(0: cg/pcg/defcg/defpcg; eigCG family: 1 + kind + 8*spdim) + loop form (fused, folded)
   bool operator<(const GraphKey &o) const {
     return std::tie(A, M, nvec, chunk, tag) < std::tie(o.A, o.M, o.nvec, o.chunk, o.tag);
+  }
+};
+
+// Host side of the persistent on-chip PCG (resident.hpp): which rows of which subdomain every workgroup owns, how many
+// of them fit into registers / LDS, and the hand-off buffers of the grid barrier.
+struct ResidentPlan {
+  int G = 0, max_rows = 0;
+  double resident_frac = 0.0;   // share of the matrix elements held in registers or LDS
+  bool usable = false;
+  unsigned epoch = 0;
+  DevBuf<ResTile> tiles;
+  DevBuf<double> part;
+  DevBuf<unsigned> flags;
+  DevBuf<int> abort;
+  std::vector<ResTile> tiles_h;
+
+  ResidentPlan(mi_ctx_s *c, const DenseBlockOp &A, const DenseBlockOp &M) {
+    hipDeviceProp_t prop;
+    MI_HIP(hipGetDeviceProperties(&prop, c->device));
+    G = env_int("MI355_RES_G", prop.multiProcessorCount);
+    const int ndl = A.maps.ndl;
+    if (G < 1 || ndl < 1 || ndl > G || G > 4 * RES_NTH) return;
+    // workgroups per subdomain in proportion to its elements, at least one each, G in all
+    std::vector<double> wgt(ndl);
+    double tot = 0.0;
+    for (int d = 0; d < ndl; ++d) { wgt[d] = (double)A.maps.nd[d] * A.ld_h[d]; tot += wgt[d]; }
+    if (tot <= 0.0) return;
+    std::vector<int> gd(ndl);
+    int used = 0;
+    for (int d = 0; d < ndl; ++d) { gd[d] = std::max(1, (int)(G * wgt[d] / tot)); used += gd[d]; }
+    while (used > G) {   // over-subscribed by the "at least one" rule: take from the subdomain with the fewest rows per workgroup
+      int best = -1; double v = 1e300;
+      for (int d = 0; d < ndl; ++d) if (gd[d] > 1 && wgt[d] / gd[d] < v) { v = wgt[d] / gd[d]; best = d; }
+      if (best < 0) return;
+      --gd[best]; --used;
+    }
+    while (used < G) {   // hand the spare workgroups to the subdomains with the most elements per workgroup
+      int best = 0; double v = -1.0;
+      for (int d = 0; d < ndl; ++d) if (wgt[d] / gd[d] > v) { v = wgt[d] / gd[d]; best = d; }
+      ++gd[best]; ++used;
+    }
+    for (int d = 0; d < ndl; ++d) {
+      const int n_d = A.maps.nd[d], ld = A.ld_h[d];
+      if (ld != M.ld_h[d] || (ld + 127) / 128 > RES_MAX_U) return;
+      const int rpw = (n_d + gd[d] - 1) / gd[d];
+      for (int k = 0; k < gd[d]; ++k) {
+        ResTile t{};
+        t.matS = A.moff_h[d]; t.matP = M.moff_h[d];
+        t.n = n_d; t.ld = ld; t.loc_off = A.maps.loc_off[d];
+        t.row0 = std::min(k * rpw, n_d);
+        t.nrows = std::max(0, std::min(rpw, n_d - t.row0));
+        t.U = res_variant(std::max(1, (ld + 127) / 128));
+        max_rows = std::max(max_rows, t.nrows);
+        tiles_h.push_back(t);
+      }
+    }
+    max_rows = std::max(8, (max_rows + 7) / 8 * 8);
+    double res_el = 0.0, all_el = 0.0;
+    for (auto &t : tiles_h) {
+      const long long fixed = (long long)res_lds_fixed(t.U, max_rows), rowb = (long long)t.U * 128 * 8;
+      if (fixed > RES_LDS_BYTES) return;
+      const int cap = (int)((RES_LDS_BYTES - fixed) / rowb);
+      const int needS = std::max(0, t.nrows - RES_WAVES * res_slots_S(t.U)), needP = std::max(0, t.nrows - RES_WAVES * res_slots_P(t.U));
+      t.ldsS = std::min(needS, cap / 2);
+      t.ldsP = std::min(needP, cap - t.ldsS);
+      t.ldsS = std::min(needS, cap - t.ldsP);
+      res_el += (double)(std::min(t.nrows, RES_WAVES * res_slots_S(t.U) + t.ldsS) + std::min(t.nrows, RES_WAVES * res_slots_P(t.U) + t.ldsP)) * t.ld;
+      all_el += 2.0 * t.nrows * t.ld;
+    }
+    resident_frac = all_el > 0 ? res_el / all_el : 0.0;
+    tiles.upload(tiles_h, c->stream);
+    part.alloc((size_t)4 * G); part.zero(c->stream);
+    flags.alloc((size_t)G); flags.zero(c->stream);
+    abort.alloc(1); abort.zero(c->stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+      MI_HIP(hipFuncSetAttribute((const void *)k_pcg_resident, hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS_BYTES));
+      attr_set = true;
+    }
+    MI_HIP(hipStreamSynchronize(c->stream));
+    usable = resident_frac * 100.0 >= env_int("MI355_RES_MIN_PCT", 50);
+  }
+  void reset(hipStream_t s) {  // after an aborted launch: the flags are in an unknown state
+    flags.zero(s); abort.zero(s);
+    epoch = 0;
   }
 };
 
@@ -58,6 +144,7 @@ struct SolverWorkspace {
   hipEvent_t ev[2] = {nullptr, nullptr};
   std::map<GraphKey, hipGraphExec_t> graphs;
   std::map<GraphKey, int> predicted;  // loop iterations the last solve with this (A, M, nvec) took
+  std::map<std::pair<const Operator *, const Operator *>, std::unique_ptr<ResidentPlan>> resident;  // per (S, ΠS) pair
 
   explicit SolverWorkspace(int64_t n_) : n(n_), g(vec_grid(n_)) {
     auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -91,6 +178,9 @@ struct SolverWorkspace {
       else ++it;
     for (auto it = predicted.begin(); it != predicted.end();)
       if (it->first.A == op || it->first.M == op) it = predicted.erase(it);
+      else ++it;
+    for (auto it = resident.begin(); it != resident.end();)
+      if (it->first.first == op || it->first.second == op) it = resident.erase(it);
       else ++it;
   }
   void ensure_deflation(int nvec) {
@@ -172,6 +262,14 @@ struct Krylov {
              !Ad->scale && Md->scale && Ad->same_maps(*Md) && Ad->ntiles > 0 && Ad->max_ld <= GEMV_PANEL && Ad->maps.slot_width <= 4 &&
              (Ad->max_ld + 64 * Ad->waves - 1) / (64 * Ad->waves) <= 8 && (Md->max_ld + 64 * Md->waves - 1) / (64 * Md->waves) <= 8;
     }
+  }
+  // pcg on one GPU with both operators dense on the same maps: the whole solve as one persistent launch with the blocks
+  // held in registers / LDS (resident.hpp), when enough of them fit on the chip. nullptr: not applicable.
+  ResidentPlan *resident_plan() {
+    if (!fold || eig.tag || ctx->has_comm() || Ad->reduce_over_ranks || !env_int("MI355_RESIDENT", 0) || env_int("MI355_NO_RESIDENT", 0)) return nullptr;
+    auto &slot = ws.resident[{A, M}];
+    if (!slot) slot.reset(new ResidentPlan(ctx, *Ad, *Md));
+    return slot->usable ? slot.get() : nullptr;
   }
   PcgFold fold_args(int phase) const {
     PcgFold f{};
@@ -452,6 +550,43 @@ struct Krylov {
                          spec_res ? ws.res_stage : (double *)nullptr, (long long)ncap, &ws.flags[slot], &ws.st->x0_zero);
       MI_HIP(hipGetLastError());
     };
+    bool ran_resident = false;
+    if (ResidentPlan *rp = resident_plan()) {
+      // One persistent launch for the whole solve. It clears `done` itself only by setting it at the end: an aborted
+      // launch (bounded spin expired: the workgroups were not all resident) leaves done = 0 and the loops below take over.
+      ResArgs ra{};
+      ra.MS = Ad->M.p; ra.MP = Md->M.p; ra.tiles = rp->tiles.p; ra.gidx = Ad->maps.gidx.p; ra.cnt = Md->cnt.p;
+      ra.tgt = Ad->maps.tgt.p; ra.jrank = Ad->maps.jrank.p; ra.conS = Ad->fold_con(); ra.conP = Md->fold_con();
+      ra.part = rp->part.p; ra.flags = rp->flags.p; ra.abort = rp->abort.p; ra.st = ws.st; ra.res_norm = ws.res_norm.p;
+      ra.x = ws.x; ra.b = ws.b; ra.epoch0 = rp->epoch; ra.W = Ad->maps.slot_width; ra.G = rp->G; ra.max_rows = rp->max_rows;
+      DevBuf<long long> dbg;
+      const bool debug = env_int("MI355_RES_DEBUG", 0) != 0;
+      if (debug) { dbg.alloc(512); dbg.zero(s); ra.dbg = dbg.p; ra.dbg_wg = env_int("MI355_RES_DEBUG_WG", 0); }
+      hipLaunchKernelGGL(k_pcg_resident, dim3(rp->G), dim3(RES_NTH), RES_LDS_BYTES, s, ra);
+      MI_HIP(hipGetLastError());
+      enqueue_results(0);
+      MI_HIP(hipStreamSynchronize(s));
+      if (debug) {  // wall-clock stamps (100 MHz) of one workgroup: 5 for the set-up, then 8 per iteration
+        std::vector<long long> h(512);
+        MI_HIP(hipMemcpy(h.data(), dbg.p, 512 * sizeof(long long), hipMemcpyDeviceToHost));
+        const ResTile &tt = rp->tiles_h[ra.dbg_wg];
+        std::fprintf(stderr, "[resident] wg %d: n=%d ld=%d rows=%d U=%d regS=%d regP=%d ldsS=%d ldsP=%d resident_frac=%.3f\n", ra.dbg_wg, tt.n,
+                     tt.ld, tt.nrows, tt.U, RES_WAVES * res_slots_S(tt.U), RES_WAVES * res_slots_P(tt.U), tt.ldsS, tt.ldsP, rp->resident_frac);
+        std::fprintf(stderr, "[resident] stamps (us since start):");
+        for (int k = 0; k < 512 && h[k]; ++k) std::fprintf(stderr, "%s%.2f", (k >= 5 && (k - 5) % 8 == 0) ? "\n  " : " ", (h[k] - h[0]) * 0.01);
+        std::fprintf(stderr, "\n");
+      }
+      if (ws.flags[0].done) {
+        rp->epoch += (unsigned)(2 * ws.flags[0].it + 4);
+        ran_resident = true;
+        use_graph = false;
+      } else {
+        rp->reset(s);
+        rp->usable = false;   // this context does not get all the CUs: stay with the graph loop from now on
+        int64_t mx = maxit, cd = 0; double e = eps;
+        begin(b_in, x_io, W_in, mx, e, cd);   // x0, b and the state block as they were
+      }
+    }
     if (use_graph) {
       const GraphKey pk{A, M, nvec, 0};
       int &predicted = ws.predicted[pk];
@@ -495,7 +630,7 @@ struct Krylov {
       predicted = (int)std::max<long long>(1, ws.flags[0].it - (fold ? 0 : 1));  // the folded pair checks the stop rule one launch later
       }
     }
-    if (!use_graph) {
+    if (!use_graph && !ran_resident) {
       setup_tail();
       for (int64_t l = 0; l < maxit + 2; ++l) {
         fetch_flags(0);

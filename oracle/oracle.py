@@ -494,3 +494,73 @@ def run_assembly_plan(plan, a_nodal):
         t = term[plan.cptr[m] + p]
         out[m] = t if p == 0 else out[m] + t
     return out
+
+
+# ------------------------------------------------------------------ set_subdomains, loop by loop (EPDD.jl:86-193)
+def set_subdomains_reference(cells, cell_neighbors, epart, npart, dirichlet_nodes):
+    """Literal restatement of the reference's `set_subdomains` (Fem/EllipticPdeDomainDecomposition.jl:86-193): the same
+    element loop, segment loop and `for node in iel_cell` order, Dicts numbered by first encounter (`.count + 1`),
+    the O(n_Γ) `node in node_Γ` membership test, interiors by ascending node id in their `npart` owner. Inputs 0-based
+    (cells (3, nel), cell_neighbors with -1 on the boundary, epart, npart; `dirichlet_nodes` a set of 0-based nodes);
+    the loops run 1-based internally like the Julia code and the result is returned 0-based:
+        ind_Id_g2l, ind_Γd_g2l, ind_Γ_g2l, ind_Γd_Γ2l (lists of dicts / dict), node_owner, elemd, node_Γ, node_Γ_cnt,
+        node_Id, nnode_Id
+    Pure Python: small meshes only (test infrastructure)."""
+    cells = np.asarray(cells) + 1
+    nb = np.where(np.asarray(cell_neighbors) < 0, -1, np.asarray(cell_neighbors) + 1)
+    epart = np.asarray(epart) + 1
+    npart = np.asarray(npart) + 1
+    dirichlet = {int(v) + 1 for v in dirichlet_nodes}
+    nel = cells.shape[1]
+    nnode = int(cells.max())
+    ndom = int(epart.max())
+    ind_Id_g2l = [dict() for _ in range(ndom)]
+    ind_Γd_g2l = [dict() for _ in range(ndom)]
+    ind_Γ_g2l = {}
+    ind_Γd_Γ2l = [dict() for _ in range(ndom)]
+    node_owner = [0] * (nnode + 1)
+    elemd = [[] for _ in range(ndom)]
+    node_Γ, node_Γ_cnt = [], []
+    node_Id = [[] for _ in range(ndom)]
+    bnd_tag, iel_max = int(nb.min()), int(nb.max())          # :106-111 (TriangleMesh's off-by-one convention)
+    if iel_max > nel:
+        nb = nb - 1
+        bnd_tag = -1
+    for iel in range(1, nel + 1):                              # :114
+        iel_cell = [int(v) for v in cells[:, iel - 1]]
+        idom = int(epart[iel - 1])
+        elemd[idom - 1].append(iel)
+        for j in range(3):                                     # :123
+            jel = int(nb[j, iel - 1])
+            if jel != bnd_tag:
+                jdom = int(epart[jel - 1])
+                if jdom != idom:
+                    jel_cell = [int(v) for v in cells[:, jel - 1]]
+                    for node in iel_cell:                      # :135
+                        if (node in jel_cell) and (node not in dirichlet):
+                            if node not in ind_Γd_g2l[idom - 1]:
+                                ind_Γd_g2l[idom - 1][node] = len(ind_Γd_g2l[idom - 1]) + 1
+                            if node not in node_Γ:             # :152 (linear search in the reference)
+                                node_Γ.append(node)
+                                node_Γ_cnt.append(0)
+                                ind_Γ_g2l[node] = len(ind_Γ_g2l) + 1
+                                node_owner[node] = -1
+    for inode in range(1, nnode + 1):                          # :166-173
+        if (inode not in dirichlet) and node_owner[inode] != -1:
+            idom = int(npart[inode - 1])
+            node_Id[idom - 1].append(inode)
+            node_owner[inode] = idom
+    nnode_Id = [len(v) for v in node_Id]
+    for idom in range(ndom):                                   # :176-181
+        for i, node in enumerate(node_Id[idom]):
+            ind_Id_g2l[idom][node] = i + 1
+    for idom in range(ndom):                                   # :184-190
+        for gnode, l_in_Γd in ind_Γd_g2l[idom].items():
+            l_in_Γ = ind_Γ_g2l[gnode]
+            node_Γ_cnt[l_in_Γ - 1] += 1
+            ind_Γd_Γ2l[idom][l_in_Γ] = l_in_Γd
+    z = lambda d: {k - 1: v - 1 for k, v in d.items()}         # noqa: E731  back to 0-based keys and values
+    owner0 = np.array([(-2 if (i in dirichlet) else (-1 if node_owner[i] == -1 else node_owner[i] - 1)) for i in range(1, nnode + 1)])
+    return ([z(d) for d in ind_Id_g2l], [z(d) for d in ind_Γd_g2l], z(ind_Γ_g2l), [z(d) for d in ind_Γd_Γ2l], owner0,
+            [np.array(e, dtype=np.int64) - 1 for e in elemd], np.array(node_Γ, dtype=np.int64) - 1,
+            np.array(node_Γ_cnt, dtype=np.int64), [np.array(v, dtype=np.int64) - 1 for v in node_Id], nnode_Id)

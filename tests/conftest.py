@@ -91,3 +91,36 @@ def lowest_eigvecs(orc_op, n, nev):
 def ctx(pkg):
     """GPU context; only -m gpu tests request it."""
     return pkg.api.Context(0)
+
+
+def unstructured_mesh(fem, N=28, nsec=6, seed=11):
+    """A mesh + partition shaped like the output of the reference's Triangle + METIS pipeline as far as any code can
+    tell: jittered interior nodes, node and element numbers randomly permuted, vertex order rotated per element, and
+    `nsec` pie-slice subdomains that all meet at one interior node (multiplicity nsec there — box partitions stop at 4).
+    Returns (Mesh, epart, npart), everything 0-based."""
+    rng = np.random.default_rng(seed)
+    m = fem.get_mesh(N)
+    nnode, nel = m.points.shape[1], m.cells.shape[1]
+    h = 1.0 / (N - 1)
+    pts = m.points.copy()
+    interior = m.point_marker == 0
+    pts[:, interior] += rng.uniform(-0.22 * h, 0.22 * h, size=(2, int(interior.sum())))
+    cx, cy = pts[:, (N // 2) * N + N // 2]                       # the hub: an interior NODE, so every slice touches it
+    cen = pts[:, m.cells].mean(axis=1)                           # (2, nel) centroids
+    ang = np.arctan2(cen[1] - cy, cen[0] - cx) + 0.4
+    epart = np.floor((ang % (2 * np.pi)) / (2 * np.pi / nsec)).astype(np.int64) % nsec
+    # renumber nodes and elements, rotate vertex order (orientation kept; the neighbour table rotates with it)
+    pn, pe = rng.permutation(nnode), rng.permutation(nel)       # new id of old node / new position -> old element
+    inv_e = np.empty(nel, dtype=np.int64); inv_e[pe] = np.arange(nel)
+    cells, nb = pn[m.cells][:, pe], m.cell_neighbors[:, pe]
+    nb = np.where(nb < 0, -1, inv_e[np.maximum(nb, 0)])
+    rot = rng.integers(0, 3, nel)
+    idx = (np.arange(3)[:, None] + rot[None, :]) % 3
+    cells, nb = np.take_along_axis(cells, idx, 0), np.take_along_axis(nb, idx, 0)
+    points = np.empty_like(pts); points[:, pn] = pts
+    marker = np.empty_like(m.point_marker); marker[pn] = m.point_marker
+    epart = epart[pe]
+    npart = np.full(nnode, -1, dtype=np.int64)
+    for k in range(3):
+        npart[cells[k]] = epart                                  # any owning element's subdomain (mpmetis gives one of them)
+    return fem.Mesh(cells, points, marker, nb, N), epart, npart

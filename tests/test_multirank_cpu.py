@@ -114,3 +114,24 @@ def test_two_rank_sharded_pcg_matches_single_rank(tmp_path, fem, orc, replicate_
     assert int(r0["it"]) == it
     assert np.allclose(r0["res"], res, rtol=1e-8, atol=1e-12 * res[0])
     assert np.linalg.norm(r0["x"] - x) <= 1e-6 * np.linalg.norm(x)
+
+
+def test_bench_launcher_spawns_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts the ranks itself (fresh children, before
+    any GPU call, rendezvous on 127.0.0.1). Checked on the CPU with --launcher-selftest: the children do a gloo
+    all-reduce instead of the benchmark and rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for n in (2, 3):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--launcher-selftest"],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out == {"launcher": "ok", "n_gpus": n, "sum": n * (n + 1) / 2, "master": "127.0.0.1"}
+    # under a launcher (WORLD_SIZE set) a mismatch with --gpus is still refused
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                       capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0"), timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

@@ -381,3 +381,35 @@ def test_assembly_plan_reproduces_prepare_local_schurs(fem, orc, px, py):
         for u, v in zip(got[3], want[3]):
             assert np.array_equal(u, v)
         assert np.array_equal(got[4], want[4])
+
+
+# ------------------------------------------------------------------ set_subdomains against its loop-by-loop restatement
+@pytest.mark.parametrize("case", ["boxes", "strips", "pie5", "pie7"])
+def test_set_subdomains_matches_the_reference_loops(fem, orc, case):
+    """The vectorised host mirror `fem.set_subdomains` against `oracle.set_subdomains_reference`, a literal transcription
+    of EPDD.jl:86-193 (Dicts numbered by first encounter, element/segment/vertex loop order): every map, on box
+    partitions and on an unstructured-numbered mesh with pie-slice subdomains meeting at one node (multiplicity 5)."""
+    from conftest import unstructured_mesh
+    if case == "boxes":
+        mesh = fem.get_mesh(19); epart, npart = fem.mesh_partition(mesh, 3, 2)
+    elif case == "strips":
+        mesh = fem.get_mesh(17); epart, npart = fem.mesh_partition(mesh, 1, 4)
+    else:
+        mesh, epart, npart = unstructured_mesh(fem, 16 if case == "pie5" else 21, int(case[3:]), seed=3)
+    d = fem.get_dirichlet_inds(mesh.points, mesh.point_marker)
+    sub = fem.set_subdomains(mesh.cells, mesh.cell_neighbors, epart, npart, d.dirichlet_g2l)
+    dirichlet = set(np.flatnonzero(d.dirichlet_g2l >= 0).tolist())
+    (ind_Id_g2l, ind_Γd_g2l, ind_Γ_g2l, ind_Γd_Γ2l, owner, elemd, node_Γ, node_Γ_cnt, node_Id, nnode_Id) = \
+        orc.set_subdomains_reference(mesh.cells, mesh.cell_neighbors, epart, npart, dirichlet)
+    assert np.array_equal(sub.node_Γ, node_Γ) and np.array_equal(sub.node_Γ_cnt, node_Γ_cnt)
+    assert np.array_equal(sub.node_owner, owner)
+    assert sub.n_Id == nnode_Id
+    for dd in range(sub.ndom):
+        assert np.array_equal(sub.elemd[dd], elemd[dd]) and np.array_equal(sub.node_Id[dd], node_Id[dd])
+        # Γ_d numbering: node_Γd[l] is the node whose Dict value is l; gather_idx is the flattened ind_Γd_Γ2l
+        assert {int(g): l for l, g in enumerate(sub.node_Γd[dd])} == ind_Γd_g2l[dd]
+        assert {int(g): l for l, g in enumerate(sub.gather_idx[dd])} == ind_Γd_Γ2l[dd]
+        assert {int(g): int(sub.ind_I_g2l[g]) for g in sub.node_Id[dd]} == ind_Id_g2l[dd]
+    assert {int(g): int(sub.ind_Γ_g2l[g]) for g in sub.node_Γ} == ind_Γ_g2l
+    if case.startswith("pie"):
+        assert sub.node_Γ_cnt.max() >= 5

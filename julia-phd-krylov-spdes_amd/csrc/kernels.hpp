@@ -244,6 +244,196 @@ __global__ __launch_bounds__(NT) void k_spmv_csr(int nblocks, const SpmvBlock *_
   }
 }
 
+// ------------------------------------------------------------------ pcg on a sparse matrix in 2 launches per iteration
+// Config 2 (`pcg(A, b, x, M)` on the full matrix, M diagonal or absent; cg.jl:67-109 / 14-50). The three launches of the
+// generic loop (SpMV + p'Ap, x/r/z update, p update) become two, and every vector element is written on the XCD that
+// reads it next:
+//   k_spmv_pcg     : r'r, r'z from the partials -> it += 1, res_norm[it], stop rule, beta (cg.jl:91, 102-106); then the
+//                    CSR-stream SpMV of the NEW direction without materialising it first: a gathered entry is
+//                    beta*p_old[c] + z[c], computed on the fly from the interleaved pair (p_old[c], z[c]) — one 16-byte
+//                    gather per non-zero, the same arithmetic (hence bits) in every workgroup; the row owner stores
+//                    p_new[r]; Ap[r]; per-block partial p'Ap (cg.jl:93-94).
+//   k_update_xr_blk: alpha = r'z / p'Ap; x += alpha p; r -= alpha Ap; z = M \ r (diagonal); per-block partials r'r, r'z
+//                    (cg.jl:95-101), one workgroup per row block with the SpMV's block -> XCD mapping.
+// The pairs live in two buffers used alternately (parity of `it`), so no launch reads what it writes; scalars follow the
+// it / it_nxt, rTz / rTz_prev hand-off of the folded Schur loop. Start-up: it = 0, p = 0, rTz_prev = 1, so the first
+// k_spmv_pcg produces it = 1, res_norm[1] = ||r_0||, p = z_0.
+__device__ __forceinline__ int spmv_block_of(int nblocks) {
+  const int per = (nblocks + 7) >> 3;
+  return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+}
+__global__ __launch_bounds__(NT, 8) void k_spmv_pcg(int nblocks, const SpmvBlock *__restrict__ blk, const int *__restrict__ rowptr,
+                                                 const int *__restrict__ col, const double *__restrict__ val, SolverState *st,
+                                                 const double *part_rr, const double *part_rz, int g_vec, double *pz0, double *pz1,
+                                                 double *__restrict__ Ap, double *__restrict__ part_pAp, double *res_norm,
+                                                 int precond) {
+  if (st->done) return;
+  __shared__ __attribute__((aligned(16))) double prod[SPMV_TILE];
+  __shared__ double sm[NT / 64 + 1];
+  const int b = spmv_block_of(nblocks);
+  const bool has = b < nblocks;
+  const SpmvBlock bi = has ? blk[b] : SpmvBlock{0, 0, 0, 0};
+  const int r0 = bi.r0, r1 = bi.r1, k0 = bi.k0, nnz = bi.k1 - k0;
+  const long long it0 = st->it, maxit = st->maxit, cap = st->res_cap;
+  const double tol = st->tol, old = precond ? st->rTz_prev : st->rTr_prev;
+  const double2 *pz_old = reinterpret_cast<const double2 *>((it0 & 1) ? pz1 : pz0);
+  double2 *pz_new = reinterpret_cast<double2 *>((it0 & 1) ? pz0 : pz1);
+  // everything that does not depend on beta is requested before the reduction: this thread's non-zeros (SPMV_TILE / NT
+  // of them) with their gathered pairs, and the bounds and pairs of its first two rows
+  constexpr int KPT = SPMV_TILE / NT;
+  double vv[KPT];
+  double2 gp[KPT];
+  const bool fits = nnz <= SPMV_TILE;
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    const int k = q * NT + (int)threadIdx.x;
+    vv[q] = 0.0; gp[q] = make_double2(0.0, 0.0);
+    if (fits && k < nnz) { vv[q] = val[k0 + k]; gp[q] = pz_old[col[k0 + k]]; }
+  }
+  const int ra = r0 + threadIdx.x;
+  int a0 = 0, e0 = 0;
+  double2 o0 = make_double2(0.0, 0.0);
+  if (ra < r1) { a0 = rowptr[ra] - k0; e0 = rowptr[ra + 1] - k0; o0 = pz_old[ra]; }
+  // ---- scalars (identical in every workgroup): g_vec <= NT partials per sum, one load per thread, one barrier for both
+  double rr = (int)threadIdx.x < g_vec ? part_rr[threadIdx.x] : 0.0;
+  double rz = (precond && (int)threadIdx.x < g_vec) ? part_rz[threadIdx.x] : 0.0;
+  __shared__ double sm2[2 * (NT / 64)];
+  block_sum2_t<NT>(rr, rz, sm2);
+  if (!precond) rz = rr;
+  double beta = 1. / old;
+  beta *= rz;
+  const long long it_new = it0 + 1;
+  const double res = sqrt(rr);
+  const bool over = it_new > cap;
+  const bool stop = over || !((it_new < maxit) && (res > tol));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->rTr = rr; st->rTz = rz; st->beta = beta;
+    st->it_nxt = it_new;
+    if (!over) res_norm[it_new - 1] = res; else st->overflow = 1;
+    if (stop) st->done = 1;
+  }
+  if (stop || !has) return;
+  double wy = 0.0;
+  if (fits) {
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+      const int k = q * NT + (int)threadIdx.x;
+      if (k < nnz) prod[k] = vv[q] * (beta * gp[q].x + gp[q].y);       // A[r,c] * (beta p + z)[c]
+    }
+    __syncthreads();
+    for (int r = ra, i = 0; r < r1; r += NT, ++i) {
+      int a, e;
+      double2 o;
+      if (i == 0) { a = a0; e = e0; o = o0; }
+      else { a = rowptr[r] - k0; e = rowptr[r + 1] - k0; o = pz_old[r]; }
+      double sum = 0.0;
+      for (int k = a; k < e; ++k) sum += prod[k];                      // left to right: the CSC scatter order (bit-exact)
+      const double pn = beta * o.x + o.y;                              // axpby!(1, z, beta, p)
+      Ap[r] = sum;
+      pz_new[r].x = pn;
+      wy += pn * sum;
+    }
+  } else {  // one row longer than the tile: tile by tile, thread 0 keeps the running sum
+    double sum = 0.0;
+    for (int t0 = 0; t0 < nnz; t0 += SPMV_TILE) {
+      const int m = min(SPMV_TILE, nnz - t0);
+      for (int k = threadIdx.x; k < m; k += NT) {
+        const double2 g = pz_old[col[k0 + t0 + k]];
+        prod[k] = val[k0 + t0 + k] * (beta * g.x + g.y);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0)
+        for (int k = 0; k < m; ++k) sum += prod[k];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const double2 o = pz_old[r0];
+      const double pn = beta * o.x + o.y;
+      Ap[r0] = sum;
+      pz_new[r0].x = pn;
+      wy = pn * sum;
+    }
+  }
+  wy = block_sum(wy, sm);
+  if (threadIdx.x == 0) part_pAp[b] = wy;
+}
+// Grid = 8 * nj workgroups: workgroup k works on XCD k & 7 (blocks are dealt round-robin over the XCDs) and takes the
+// (k >> 3)-th of nj equal slices of the rows whose SpMV row blocks run on that XCD (`xcd_row[x] .. xcd_row[x + 1]`), so
+// that z, r, x are written into the L2 that k_spmv_pcg's gathers and row sums read them from.
+__global__ __launch_bounds__(NT) void k_update_xr_blk(const int *__restrict__ xcd_row, SolverState *st, const double *part_pAp,
+                                                      int nblocks, double *pz0, double *pz1, const double *__restrict__ Ap,
+                                                      double *__restrict__ x, double *__restrict__ r,
+                                                      const double *__restrict__ dinv, int diag, int precond,
+                                                      double *__restrict__ part_rr, double *__restrict__ part_rz) {
+  if (st->done) return;
+  __shared__ double sm[NT / 64 + 1];
+  const int xc = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
+  const long long R0 = xcd_row[xc], R1 = xcd_row[xc + 1];
+  const int lo = (int)(R0 + (R1 - R0) * j / nj), hi = (int)(R0 + (R1 - R0) * (j + 1) / nj);
+  const long long it_n = st->it_nxt;
+  const double num = precond ? st->rTz : st->rTr, rTr0 = st->rTr, rTz0 = st->rTz;
+  double2 *pz = reinterpret_cast<double2 *>((it_n & 1) ? pz1 : pz0);     // the pairs k_spmv_pcg has just written p into
+  // the first four rows of this thread: loads ahead of the reduction
+  double pv[4], av[4], xv[4], rv[4], dv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int rw = lo + k * NT + (int)threadIdx.x;
+    const bool ok = rw < hi;
+    pv[k] = ok ? pz[rw].x : 0.0; av[k] = ok ? Ap[rw] : 0.0; xv[k] = ok ? x[rw] : 0.0; rv[k] = ok ? r[rw] : 0.0;
+    dv[k] = ok && diag == 2 ? dinv[rw] : 1.0;
+  }
+  const double d = sum_partials(part_pAp, nblocks, sm);
+  const double alpha = num / d;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->d = d; st->alpha = alpha;
+    st->rTr_prev = rTr0; st->rTz_prev = rTz0;
+    st->it = it_n;
+  }
+  double srr = 0.0, srz = 0.0;
+  for (int rw = lo + (int)threadIdx.x, i = 0; rw < hi; rw += NT, ++i) {
+    double p_, a_, x_, r_, d_;
+    if (i < 4) { p_ = pv[i]; a_ = av[i]; x_ = xv[i]; r_ = rv[i]; d_ = dv[i]; }
+    else { p_ = pz[rw].x; a_ = Ap[rw]; x_ = x[rw]; r_ = r[rw]; d_ = diag == 2 ? dinv[rw] : 1.0; }
+    x[rw] = x_ + alpha * p_;                     // axpy!(alpha, p, x)
+    const double ri = r_ + (-alpha) * a_;        // axpy!(-alpha, Ap, r)
+    r[rw] = ri;
+    const double zi = diag == 2 ? d_ * ri : ri;  // z .= M \ r
+    pz[rw].y = zi;
+    srr += ri * ri;
+    srz += ri * zi;
+  }
+  srr = block_sum(srr, sm);
+  srz = block_sum(srz, sm);
+  if (threadIdx.x == 0) { part_rr[blockIdx.x] = srr; part_rz[blockIdx.x] = srz; }
+}
+// Start-up of that loop after r_0 (and z_0) exist: pairs (0, z_0) into buffer 0; the g_vec partials = (r'r, r'z, 0, 0, ...);
+// scalars as k_fused_residual<., true> leaves them for the folded Schur loop.
+__global__ __launch_bounds__(NT) void k_csrfold_start(int n, int g_vec, SolverState *st, const double *part_rr_in,
+                                                      const double *part_bb_in, const double *part_rz_in, int g_in,
+                                                      const double *__restrict__ z, double *__restrict__ pz0,
+                                                      double *__restrict__ part_rr, double *__restrict__ part_rz) {
+  __shared__ double sm[NT / 64 + 1];
+  for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    pz0[2 * (long long)i] = 0.0;
+    pz0[2 * (long long)i + 1] = z[i];
+  }
+  for (int i = blockIdx.x * NT + threadIdx.x; i < g_vec; i += gridDim.x * NT)
+    if (i > 0) { part_rr[i] = 0.0; part_rz[i] = 0.0; }
+  if (blockIdx.x == 0) {
+    const double eps = st->eps;
+    const double rr = sum_partials(part_rr_in, g_in, sm);
+    const double bb = sum_partials(part_bb_in, g_in, sm);
+    const double rz = part_rz_in ? sum_partials(part_rz_in, g_in, sm) : rr;
+    if (threadIdx.x == 0) {
+      part_rr[0] = rr; part_rz[0] = rz;
+      st->rTr = rr; st->rTz = rz; st->rTr_prev = 1.0; st->rTz_prev = 1.0;
+      st->bnorm = sqrt(bb); st->tol = eps * st->bnorm;
+      st->it = 0; st->it_nxt = 0; st->done = 0; st->overflow = 0;
+      st->d = 0.0; st->alpha = 0.0; st->beta = 0.0;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ interior CG on the device
 // The reference's matrix-free Schur applies solve A_IIdd v = A_IΓdd xd with `IterativeSolvers.cg(A, b; reltol)`
 // (EPDD.jl:648-650; third-party, restated from its published iteration, IterativeSolvers.jl cg.jl `CGIterable`):
@@ -649,6 +839,13 @@ struct PcgFold {
   const int *jrank;         // [nloc] rank of this subdomain among the contributors of the node (0 = owner)
   int W;
   int part_rows;            // PHASE 0 writes its partial dot per row (local order, nloc entries) instead of per tile
+  // deflation (defcg.jl:291-305; nvec == 0: plain pcg). PHASE 1 also leaves per-tile partials of WtA*z; k_defl_mu turns
+  // them into mu = WtAW \ (WtA*z) and (W*mu) in local order; PHASE 0 subtracts that from beta*p + z.
+  int nvec;
+  long long n_gamma;
+  const double *AW;         // [nvec * n_Γ] WtA[v, :] = A*W[:, v], Γ order
+  double *part_mu;          // [nvec * ntiles(ΠS)] layout v * ntiles + tile
+  const double *wm_loc;     // [nloc] (W*mu)[gidx[loc]]
 };
 __device__ __forceinline__ double slot_sum(const double *slots, int g, int W) {
   double s = 0.0;
@@ -674,10 +871,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
   __shared__ double sm[2 * (NTH / 64)];
   __shared__ double rowv[NR], rowc0[NR], rowc1[NR];
+  __shared__ double rowy[NR];   // deflation: the rows' z-contributions
+  __shared__ int rowg[NR];      //            and their Γ indices
   const GemvTile t = m.tiles[blockIdx.x];
   const int off = t.loc_off, W = f.W, n = t.n;
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
-  if (threadIdx.x < NR) { rowc0[threadIdx.x] = 0.0; rowv[threadIdx.x] = 0.0; }  // visible after the barrier of the sums
+  if (threadIdx.x < NR) { rowc0[threadIdx.x] = 0.0; rowv[threadIdx.x] = 0.0; rowy[threadIdx.x] = 0.0; rowg[threadIdx.x] = 0; }  // visible after the barrier of the sums
   GemvRows<RPW> rows;
 #if !MI355_OPERAND_FIRST
   if (t.active) rows.begin(m, t);  // matrix stream in flight from here on
@@ -699,16 +898,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
 #pragma unroll
     for (int k = 0; k < 8; ++k) { pa += ta[k]; if (PHASE == 0) pb += tb[k]; }
   }
-  double cv[FOLD_CPT], cs[FOLD_CPT], cc[FOLD_CPT];  // vector value, Γ-sum of the contributions, cnt — per column
+  double cv[FOLD_CPT], cs[FOLD_CPT], cc[FOLD_CPT];  // vector value, Γ-sum of the contributions, cnt (PHASE 0: W*mu) — per column
 #pragma unroll
   for (int q = 0; q < FOLD_CPT; ++q) {
     const int j = q * NTH + threadIdx.x;
-    cv[q] = cs[q] = 0.0; cc[q] = 1.0;
+    cv[q] = cs[q] = 0.0; cc[q] = PHASE == 1 ? 1.0 : 0.0;
     if (j < n) {
       const int loc = off + j;
       cs[q] = slot_sum(f.con_in, loc, W);
       if (PHASE == 1) { cv[q] = first1 ? f.r_gamma[m.gidx[loc]] : f.r_cur[loc]; cc[q] = m.cnt[loc]; }
-      else cv[q] = f.p_cur[loc];
+      else { cv[q] = f.p_cur[loc]; if (f.nvec > 0) cc[q] = f.wm_loc[loc]; }
     }
   }
   // The thread whose column j is also a row of this tile serves that row (at most one column per thread:
@@ -794,12 +993,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
         // values, and 0 * NaN left there by a solve that ended non-finite would poison every later solve)
         v = PHASE == 1 ? (first1 ? cv[q] : cv[q] + (-coef) * cs[q])   // r - alpha*Ap
                        : coef * cv[q] + cs[q];                        // beta*p + z
+        if (PHASE == 0 && f.nvec > 0) v = v - cc[q];                  // ... - W*mu (defcg.jl:303)
         vs = PHASE == 1 ? v / cc[q] : v;
       }
       xs[j] = vs;
       if (q == o_q) {
         const int ri = j - t.row0;
         if (t.active) rowv[ri] = v;
+        if (PHASE == 1 && f.nvec > 0) rowg[ri] = o_g;
         if (o_own) {                                      // owner of this Γ node
           if (PHASE == 1) {
             if (t.active) rowc0[ri] = v * v;
@@ -842,6 +1043,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
         }
       }
       rowc1[ri] = (r < n ? rowv[ri] : 0.0) * y;    // r_g * z-contribution  /  p_g * Ap-contribution
+      if (PHASE == 1) rowy[ri] = y;
     }
   }
   if (PHASE == 1 && o_q >= 0 && o_own) f.x[o_g] = o_x + coef * o_a;  // x + alpha*p (cg.jl:97), off the critical path
@@ -851,6 +1053,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     // does not depend on how each rank tiles its blocks, so the ranks' arrays add up to the full one
     if (threadIdx.x < NR && t.row0 + (int)threadIdx.x < n) f.part_out0[off + t.row0 + threadIdx.x] = rowc1[threadIdx.x];
     return;
+  }
+  if (PHASE == 1 && f.nvec > 0 && (int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + f.nvec) {
+    // per-tile partial of WtA*z (defcg.jl:301): sum over this tile's rows of WtA[v, g(row)] * (z-contribution of the row);
+    // the second wave does it while the first one reduces the dot products (nvec <= 64)
+    const int v = (int)threadIdx.x - 64;
+    const double *aw = f.AW + (long long)v * f.n_gamma;
+    double s = 0.0;
+    for (int i0 = 0; i0 < NR; i0 += 8) {
+      double a[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] = i0 + k < NR ? aw[rowg[i0 + k]] : 0.0;   // rows beyond the tile: rowy = 0, rowg = 0
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + k < NR) s += a[k] * rowy[i0 + k];
+    }
+    f.part_mu[(long long)v * gridDim.x + blockIdx.x] = s;
   }
   if (threadIdx.x < 64) {  // per-tile partials of the next dot products: one shuffle tree over the NR row terms
     double a = 0.0, b = 0.0;
@@ -1168,6 +1386,112 @@ __device__ __forceinline__ double wave_lu_solve(int nvec, const double *__restri
   }
   return b;
 }
+// The same solve with this lane's row of the factors in registers and the exchanged values read with v_readlane
+// (uniform lane index): a step of the 3*nvec-long dependency chain costs a few cycles instead of an LDS round trip.
+__device__ __forceinline__ double lane_read(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+template <int NV>
+__device__ __forceinline__ double wave_lu_solve_reg(int nvec, const double *lu_s, const int *piv_s, double b) {
+  const int lane = threadIdx.x & 63;
+  double row[NV];                                    // LU[lane, 0:nvec]
+#pragma unroll
+  for (int k = 0; k < NV; ++k) row[k] = (k < nvec && lane < nvec) ? lu_s[lane + k * nvec] : 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (k < nvec) {
+      const int pk = __builtin_amdgcn_readfirstlane(piv_s[k]);
+      const double vk = lane_read(b, k), vp = lane_read(b, pk);
+      if (pk != k) { if (lane == k) b = vp; else if (lane == pk) b = vk; }
+    }
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (k < nvec) {
+      const double bk = lane_read(b, k);
+      if (lane > k && lane < nvec) b -= bk * row[k];
+    }
+#pragma unroll
+  for (int k = NV - 1; k >= 0; --k)
+    if (k < nvec) {
+      if (lane == k) b /= row[k];
+      const double bk = lane_read(b, k);
+      if (lane < k) b -= bk * row[k];
+    }
+  return b;
+}
+
+// Folded Def-PCG, between the ΠS and the S launch: mu = WtAW \ (WtA*z) from the per-tile partials (every workgroup
+// solves the same nvec x nvec system with the LU factors staged in LDS, nvec <= 64), then
+// wm_loc[loc] = (W*mu)[gidx[loc]] in column-axpy order (`W * mu`, defcg.jl:303) for this workgroup's slice of the
+// local positions, where the S launch reads it contiguously. 1024 threads: 16 per deflation vector for the sums.
+__global__ __launch_bounds__(1024) void k_defl_mu(const SolverState *st, int nvec, int ntiles, const double *__restrict__ part_mu,
+                                                  const double *__restrict__ LU, const int *__restrict__ piv,
+                                                  const double *__restrict__ W, long long n_gamma, int nloc,
+                                                  const int *__restrict__ gidx, double *__restrict__ wm_loc,
+                                                  double *__restrict__ mu_out) {
+  if (st->done) return;
+  __shared__ double lu_s[64 * 64];
+  __shared__ int piv_s[64];
+  __shared__ double mu_s[64];
+  for (int i = threadIdx.x; i < nvec * nvec; i += 1024) lu_s[i] = LU[i];
+  if ((int)threadIdx.x < nvec) piv_s[threadIdx.x] = piv[threadIdx.x];
+  // W entries of this thread's local position: independent of mu, requested before the solve
+  const int loc = blockIdx.x * 1024 + threadIdx.x;
+  const long long g = loc < nloc ? gidx[loc] : 0;
+  double w0[20];                                        // the first 20 columns of W at g: in flight during the sums and the solve
+#pragma unroll
+  for (int u = 0; u < 20; ++u) w0[u] = (u < nvec && loc < nloc) ? W[(long long)u * n_gamma + g] : 0.0;
+  // rhs[v] = sum over tiles: TPV = 1024 / (nvec rounded up to a power of two) threads per vector, every thread's
+  // partials requested in one batch, then a TPV-lane shuffle tree (fixed order: deterministic)
+  int vpad = 1;
+  while (vpad < nvec) vpad <<= 1;
+  const int tpv = 1024 / vpad;                          // 16 .. 1024, a power of two
+  const int v = threadIdx.x / tpv, l16 = threadIdx.x % tpv;
+  double s = 0.0;
+  if (v < nvec)
+    for (int i0 = l16; i0 < ntiles; i0 += tpv * 16) {
+      double a[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k] = i0 + tpv * k < ntiles ? part_mu[(long long)v * ntiles + i0 + tpv * k] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += a[k];
+    }
+  if (tpv > 64) {                                       // few vectors: finish across waves through LDS
+    s = wave_sum(s);
+    __shared__ double wsum[16];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (l16 == 0 && v < nvec) { s = 0.0; for (int k = 0; k < tpv / 64; ++k) s += wsum[v * (tpv / 64) + k]; }
+  } else {
+    for (int o = tpv / 2; o > 0; o >>= 1) s += __shfl_down(s, o, tpv);
+  }
+  if (l16 == 0 && v < nvec) mu_s[v] = s;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const double rv = (int)threadIdx.x < nvec ? mu_s[threadIdx.x] : 0.0;
+    const double m = nvec <= 12 ? wave_lu_solve_reg<12>(nvec, lu_s, piv_s, rv)
+                   : nvec <= 20 ? wave_lu_solve_reg<20>(nvec, lu_s, piv_s, rv) : wave_lu_solve(nvec, lu_s, piv_s, rv);
+    mu_s[threadIdx.x] = m;
+    if (blockIdx.x == 0 && (int)threadIdx.x < nvec) mu_out[threadIdx.x] = m;
+  }
+  __syncthreads();
+  if (loc < nloc) {
+    double wm = 0.0;
+#pragma unroll
+    for (int u = 0; u < 20; ++u)
+      if (u < nvec) wm += w0[u] * mu_s[u];
+    for (int q0 = 20; q0 < nvec; q0 += 16) {      // beyond the preloaded columns: sixteen in flight per thread
+      double w[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) w[u] = q0 + u < nvec ? W[(long long)(q0 + u) * n_gamma + g] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (q0 + u < nvec) wm += w[u] * mu_s[q0 + u];
+    }
+    wm_loc[loc] = wm;
+  }
+}
+
 // z = view; r'z; beta = (1/old)*new; p = beta p + z [- W mu]; it += 1; res_norm[it]; stop rule
 // (cg.jl:44-47 / 100-106; defcg.jl:76-80 / 299-305). r'r was stored by k_fused_xr. Deflation: mu is either
 // given, or (LU != nullptr, nvec <= 64) solved here from rhs[v] = WtA[v,:].z by the first wave.

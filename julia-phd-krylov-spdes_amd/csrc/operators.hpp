@@ -56,6 +56,7 @@ struct Operator {
   }
   virtual int diag_kind(const double **dinv) const { return 0; }
   virtual DenseBlockOp *as_dense() { return nullptr; }
+  virtual struct CsrDev *as_csr() { return nullptr; }  // a plain sparse matrix (config 2): rows, row blocks, values
   virtual bool graph_safe() const { return true; }  // false: apply synchronises with the host
   // true: y is written exactly once, by the last kernel of apply(), and never read — it may then be pinned host memory
   virtual bool writes_y_once() const { return true; }
@@ -120,6 +121,7 @@ struct CsrDev {
   int64_t nnz = 0;
   DevBuf<int> rowptr, col;
   DevBuf<SpmvBlock> blk;
+  DevBuf<int> xcd_row;  // [9] first row of the row blocks that run on XCD x (x = blockIdx & 7); [8] = n_rows
   DevBuf<double> val;
   std::vector<SpmvBlock> blocks_h;
   // `breaks` (ascending row indices): a row block never crosses one of them (per-subdomain partial sums)
@@ -144,6 +146,12 @@ struct CsrDev {
     }
     nblocks = (int)blocks.size();
     blocks_h = blocks;
+    {  // rows whose blocks run on XCD x (k_spmv_csr deals block b = (blockIdx & 7) * per + (blockIdx >> 3))
+      const int per = (nblocks + 7) >> 3;
+      std::vector<int> xr(9, n_rows);
+      for (int x = 0; x < 8; ++x) xr[x] = x * per < nblocks ? blocks[(size_t)x * per].r0 : n_rows;
+      xcd_row.upload(xr, s);
+    }
     std::vector<int> rp = h.rowptr;
     if (rp.empty()) rp.push_back(0);
     rowptr.upload(rp, s); col.upload(h.col, s); val.upload(h.val, s); blk.upload(blocks, s);
@@ -175,6 +183,7 @@ struct CsrOp : Operator {
   }
   DevBuf<double> dot_part;
   void apply(const double *x, double *y, const int *done) override { A.launch(0, x, nullptr, y, done, ctx->stream); }
+  CsrDev *as_csr() override { return &A; }
   bool apply_dot(const double *x, double *y, const double *w, const double **part, int *count, const int *done) override {
     if (A.nblocks == 0) return false;
     A.launch(0, x, nullptr, y, done, ctx->stream, w, dot_part.p);

@@ -24,6 +24,7 @@ namespace mi {
 
 
 constexpr int64_t RES_STAGE = 8192;
+constexpr int CF_VEC_GRID = 256;  // workgroups of the vector half of the 2-launch sparse pcg (8 XCDs x 32) = partials per dot (<= NT)
 
 struct GraphKey {
   const Operator *A, *M;
@@ -131,6 +132,8 @@ struct SolverWorkspace {
   DevBuf<double> res_norm;
   // deflation
   DevBuf<double> W, AW, LU, mu, part_mu, gram;
+  DevBuf<double> fold_mu, fold_wm;  // folded Def-PCG: per-tile partials of WtA*z, (W*mu) in local order
+  DevBuf<double> cf_pz, cf_rr, cf_rz;  // 2-launch sparse pcg: two buffers of interleaved (p, z) pairs, per-block partials
   DevBuf<int> piv;
   int nvec_cap = 0;
   // eigCG family (eig_solvers.hpp): search space V (n x spdim), A*V (eigpcg), rotation target, tvec, VtAV, ...
@@ -242,6 +245,8 @@ struct Krylov {
   hipStream_t s;
   bool fused;  // single-workgroup loop kernels (small Γ systems)
   bool fold;   // pcg with both operators dense on the same maps: vector work folded into the two GEMVs
+  CsrDev *Ac = nullptr;  // cg / pcg with a diagonal M on a plain sparse matrix: the 2-launch loop (k_spmv_pcg, k_update_xr_blk)
+  bool csrfold() const { return Ac != nullptr && !eig.tag; }
   DenseBlockOp *Ad = nullptr, *Md = nullptr;
   // eigCG family: recording kernels after every iteration (eig_solvers.hpp fills this in)
   struct EigHook {
@@ -254,19 +259,22 @@ struct Krylov {
   Krylov(mi_ctx_s *c, Operator *A_, Operator *M_, int nvec_, bool generic = false, bool allow_fold = true)
       : ctx(c), A(A_), M(M_), ws(workspace(c, A_->n)), nvec(nvec_), n((int)A_->n), g(ws.g), s(c->stream),
         fused(!generic && A_->n <= FUSED_MAX_N && !env_int("MI355_NO_FUSED", 0)), fold(false) {
-    if (fused && allow_fold && M && nvec == 0 && !env_int("MI355_NO_FOLD", 0)) {
+    if (fused && allow_fold && M && nvec <= 64 && !env_int("MI355_NO_FOLD", 0) && !(nvec > 0 && env_int("MI355_NO_FOLD_DEFL", 0))) {
       Ad = A->as_dense(); Md = M->as_dense();
       // multi-GPU: S may be sharded (built on the maps of all subdomains, inactive tiles for the other ranks' blocks)
       // while the Neumann-Neumann blocks are replicated: the S launch is then followed by one all-reduce
-      fold = Ad && Md && (!Ad->reduce_over_ranks || Ad->full_maps) && !Md->reduce_over_ranks &&
+      fold = Ad && Md && (!Ad->reduce_over_ranks || (Ad->full_maps && nvec == 0)) && !Md->reduce_over_ranks &&
              !Ad->scale && Md->scale && Ad->same_maps(*Md) && Ad->ntiles > 0 && Ad->max_ld <= GEMV_PANEL && Ad->maps.slot_width <= 4 &&
              (Ad->max_ld + 64 * Ad->waves - 1) / (64 * Ad->waves) <= 8 && (Md->max_ld + 64 * Md->waves - 1) / (64 * Md->waves) <= 8;
     }
+    const double *dv = nullptr;
+    if (!fused && nvec == 0 && A->as_csr() && A->as_csr()->nblocks > 0 && (!M || M->diag_kind(&dv) != 0) && !env_int("MI355_NO_CSRFOLD", 0))
+      Ac = A->as_csr();
   }
   // pcg on one GPU with both operators dense on the same maps: the whole solve as one persistent launch with the blocks
   // held in registers / LDS (resident.hpp), when enough of them fit on the chip. nullptr: not applicable.
   ResidentPlan *resident_plan() {
-    if (!fold || eig.tag || ctx->has_comm() || Ad->reduce_over_ranks || !env_int("MI355_RESIDENT", 0) || env_int("MI355_NO_RESIDENT", 0)) return nullptr;
+    if (!fold || nvec > 0 || eig.tag || ctx->has_comm() || Ad->reduce_over_ranks || !env_int("MI355_RESIDENT", 0) || env_int("MI355_NO_RESIDENT", 0)) return nullptr;
     auto &slot = ws.resident[{A, M}];
     if (!slot) slot.reset(new ResidentPlan(ctx, *Ad, *Md));
     return slot->usable ? slot.get() : nullptr;
@@ -279,6 +287,8 @@ struct Krylov {
     f.tgt = Ad->maps.tgt.p; f.peer = Ad->maps.peer.p; f.jrank = Ad->maps.jrank.p;
     // partial-dot arrays of the OTHER operator's launch (tilings may differ); a sharded S writes one product per row
     f.part_rows = Ad->reduce_over_ranks ? 1 : 0;
+    f.nvec = nvec; f.n_gamma = n;
+    if (nvec > 0) { f.AW = ws.AW.p; f.part_mu = ws.fold_mu.p; f.wm_loc = ws.fold_wm.p; }
     f.n_in = phase ? (f.part_rows ? Ad->maps.nloc : Ad->ntiles) : Md->ntiles;
     const bool red = Ad->reduce_over_ranks;  // the S launch's outputs are summed over the ranks before the ΠS launch reads them
     if (phase) {  // ΠS launch: reads S contributions + partial p'Ap, writes ΠS contributions + partial r'r, r'z
@@ -343,6 +353,11 @@ struct Krylov {
     if (fold) {
       // 2 launches per iteration: (alpha, x, r, z, r'z, r'r) in the ΠS GEMV; (stop rule, beta, p, Ap, p'Ap) in the S GEMV
       Md->gemv_pcg(1, fold_args(1));
+      if (nvec > 0) {  // mu = WtAW \ (WtA * z); W*mu in local order for the S launch (defcg.jl:301-303)
+        hipLaunchKernelGGL(k_defl_mu, dim3((Ad->maps.nloc + 1023) / 1024), dim3(1024), 0, s, ws.st, nvec, Md->ntiles, ws.fold_mu.p,
+                           ws.LU.p, ws.piv.p, ws.W.p, (long long)n, Ad->maps.nloc, Ad->maps.gidx.p, ws.fold_wm.p, ws.mu.p);
+        MI_HIP(hipGetLastError());
+      }
       Ad->gemv_pcg(0, fold_args(0));
       if (Ad->reduce_over_ranks) Ad->reduce_fold();  // S contributions + partial p'Ap: union over the ranks
       return;
@@ -381,6 +396,20 @@ struct Krylov {
       MI_EPT_DISPATCH(MI_CALL);                                       // beta; [mu;] p; it += 1; res_norm[it]; stop rule
 #undef MI_CALL
       if (eig.tag) eig_record();
+      MI_HIP(hipGetLastError());
+      return;
+    }
+    if (csrfold()) {
+      // sparse A, diagonal or no M: 2 launches per iteration (kernels.hpp, "pcg on a sparse matrix in 2 launches")
+      const double *dinv = nullptr;
+      const int diag = pre ? M->diag_kind(&dinv) : 0;
+      const int grid = ((Ac->nblocks + 7) / 8) * 8;
+      double *pz0 = ws.cf_pz.p, *pz1 = pz0 + 2 * (size_t)n;
+      CsrOp *co = static_cast<CsrOp *>(A);
+      hipLaunchKernelGGL(k_spmv_pcg, dim3(grid), dim3(NT), 0, s, Ac->nblocks, Ac->blk.p, Ac->rowptr.p, Ac->col.p, Ac->val.p, ws.st,
+                         ws.cf_rr.p, ws.cf_rz.p, CF_VEC_GRID, pz0, pz1, ws.Ap, co->dot_part.p, ws.res_norm.p, pre);
+      hipLaunchKernelGGL(k_update_xr_blk, dim3(CF_VEC_GRID), dim3(NT), 0, s, Ac->xcd_row.p, ws.st, co->dot_part.p, Ac->nblocks, pz0,
+                         pz1, ws.Ap, ws.x, ws.r, dinv, diag, pre, ws.cf_rr.p, ws.cf_rz.p);
       MI_HIP(hipGetLastError());
       return;
     }
@@ -426,7 +455,7 @@ struct Krylov {
     };
     if (fold) {
       AsmView vAp;
-      { Hint h(A, &ws.st->x0_zero); vAp = A->apply_view(ws.x, ws.Ap, nullptr); }
+      { Hint h(A, nvec == 0 ? &ws.st->x0_zero : nullptr); vAp = A->apply_view(ws.x, ws.Ap, nullptr); }  // deflated: x0 was updated by W*mu
 #define MI_CALL(E) hipLaunchKernelGGL((k_fused_residual<E, true>), dim3(1), dim3(NTF), 0, s, n, ws.st, vAp, ws.b, ws.r)
       MI_EPT_DISPATCH(MI_CALL);
 #undef MI_CALL
@@ -448,6 +477,19 @@ struct Krylov {
     }
     { Hint h(A, nvec == 0 ? &ws.st->x0_zero : nullptr); A->apply(ws.x, ws.Ap, nullptr); }  // deflated: x0 was updated by W*mu
     hipLaunchKernelGGL(k_residual, dim3(g), dim3(NT), 0, s, n, ws.b, ws.Ap, ws.r, ws.part_rr, ws.part_bb);
+    if (csrfold()) {
+      const double *dinv = nullptr;
+      const int diag = pre ? M->diag_kind(&dinv) : 0;
+      if (diag == 2) {
+        M->apply(ws.r, ws.z, nullptr);
+        dot_partial(ws.r, ws.z, ws.part_rz, nullptr);
+      }
+      hipLaunchKernelGGL(k_csrfold_start, dim3(g), dim3(NT), 0, s, n, CF_VEC_GRID, ws.st, ws.part_rr, ws.part_bb,
+                         diag == 2 ? ws.part_rz : (const double *)nullptr, g, diag == 2 ? ws.z : ws.r, ws.cf_pz.p, ws.cf_rr.p,
+                         ws.cf_rz.p);
+      MI_HIP(hipGetLastError());
+      return;
+    }
     const double *zz = ws.r;
     if (pre) {
       M->apply(ws.r, ws.z, nullptr);
@@ -464,7 +506,7 @@ struct Krylov {
 
   // chunk > 0: `chunk` iterations; chunk < 0: set-up tail + (-chunk) iterations.
   hipGraphExec_t graph(int chunk) {
-    GraphKey key{A, M, nvec, chunk, eig.tag * 4 + (fused ? 1 : 0) + (fold ? 2 : 0)};  // the loop form is part of the graph
+    GraphKey key{A, M, nvec, chunk, eig.tag * 8 + (fused ? 1 : 0) + (fold ? 2 : 0) + (csrfold() ? 4 : 0)};  // the loop form is part of the graph
     auto it = ws.graphs.find(key);
     if (it != ws.graphs.end()) return it->second;
     hipGraph_t gr = nullptr;
@@ -487,7 +529,7 @@ struct Krylov {
   }
 
   void fetch_flags(int slot) {
-    MI_HIP(hipMemcpyAsync(&ws.flags[slot].it, fold ? &ws.st->it_nxt : &ws.st->it, sizeof(long long),
+    MI_HIP(hipMemcpyAsync(&ws.flags[slot].it, (fold || csrfold()) ? &ws.st->it_nxt : &ws.st->it, sizeof(long long),
                           hipMemcpyDeviceToHost, s));
     MI_HIP(hipMemcpyAsync(&ws.flags[slot].done, &ws.st->done, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     MI_HIP(hipEventRecord(ws.ev[slot], s));
@@ -504,6 +546,20 @@ struct Krylov {
     cap_dev = std::max<int64_t>(1, std::min<int64_t>(maxit, (int64_t)n));
     if ((size_t)cap_dev + 1 > ws.res_norm.n) { ws.drop_graphs(); ws.res_norm.alloc((size_t)cap_dev + 1); }
     if (nvec > 0) ws.ensure_deflation(nvec);
+    if (nvec > 0 && fold) {
+      const size_t need_mu = (size_t)nvec * Md->ntiles + 1, need_wm = (size_t)Ad->maps.nloc + 1;
+      if (ws.fold_mu.n < need_mu || ws.fold_wm.n < need_wm) {
+        ws.drop_graphs();  // buffers move
+        ws.fold_mu.alloc(need_mu); ws.fold_wm.alloc(need_wm);
+      }
+    }
+    if (csrfold()) {
+      const size_t need_pz = 4 * (size_t)n + 2, need_p = (size_t)CF_VEC_GRID + 1;
+      if (ws.cf_pz.n < need_pz || ws.cf_rr.n < need_p) {
+        ws.drop_graphs();  // buffers move
+        ws.cf_pz.alloc(need_pz); ws.cf_rr.alloc(need_p); ws.cf_rz.alloc(need_p);
+      }
+    }
     const size_t vb = sizeof(double) * (size_t)n;
     hipLaunchKernelGGL(k_solve_begin, dim3(g), dim3(NT), 0, s, n, b_in, x_in, ws.b, ws.x, ws.st, eps, (long long)maxit,
                        (long long)cap_dev);
@@ -546,7 +602,7 @@ struct Krylov {
     const int64_t ncap = std::min<int64_t>(res_cap, cap_dev);
     const bool spec_res = res_host && ncap > 0 && ncap <= RES_STAGE;
     auto enqueue_results = [&](int slot) {
-      hipLaunchKernelGGL(k_solve_end, dim3(g), dim3(NT), 0, s, n, ws.st, (int)fold, ws.x, x_io, ws.res_norm.p,
+      hipLaunchKernelGGL(k_solve_end, dim3(g), dim3(NT), 0, s, n, ws.st, (int)(fold || csrfold()), ws.x, x_io, ws.res_norm.p,
                          spec_res ? ws.res_stage : (double *)nullptr, (long long)ncap, &ws.flags[slot], &ws.st->x0_zero);
       MI_HIP(hipGetLastError());
     };
@@ -627,7 +683,7 @@ struct Krylov {
         enqueue_results(0);
         MI_HIP(hipStreamSynchronize(s));
       }
-      predicted = (int)std::max<long long>(1, ws.flags[0].it - (fold ? 0 : 1));  // the folded pair checks the stop rule one launch later
+      predicted = (int)std::max<long long>(1, ws.flags[0].it - ((fold || csrfold()) ? 0 : 1));  // the folded pairs check the stop rule one launch later
       }
     }
     if (!use_graph && !ran_resident) {

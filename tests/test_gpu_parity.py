@@ -380,6 +380,47 @@ def test_folded_unfolded_and_eager_loops_agree(pkg, ctx, orc, fem):
         assert np.allclose(res, G["pcg_res_norm"], rtol=RES_RTOL, atol=RES_FLOOR * res[0])
 
 
+def test_folded_deflated_loop_and_resident_loop(pkg, ctx, orc, fem, toy, ragged, monkeypatch):
+    """defpcg(S, b, x, W, ΠSnn) in its folded form (3 launches per iteration: ΠS GEMV with the WtA*z partials, the small
+    mu / W*mu kernel, S GEMV with the p-update) against the 5-launch form it replaces and against the oracle, for one,
+    many and the maximum number of deflation vectors, zero and non-zero initial guesses; and pcg in its persistent
+    on-chip form (MI355_RESIDENT=1) against the folded graph loop. The environment is read at every solve."""
+    api = pkg.api
+    for P, nvecs in ((toy, (1, 14, 64)), (ragged, (3, 16))):
+        S, M = gpu_ops(pkg, ctx, P)
+        So, Mo = orc_ops(orc, P)
+        n, b = P.sub.n_Γ, P.b_schur
+        Wall = lowest_eigvecs(So, n, max(nvecs))
+        for nvec in nvecs:
+            W = np.asfortranarray(Wall[:, :nvec])
+            for x0 in (np.zeros(n), np.random.default_rng(nvec).standard_normal(n)):
+                want = orc.defpcg(So, b, x0, W, Mo)
+                monkeypatch.delenv("MI355_NO_FOLD_DEFL", raising=False)
+                folded = api.defpcg(S, b, x0, W, M)
+                monkeypatch.setenv("MI355_NO_FOLD_DEFL", "1")
+                unfolded = api.defpcg(S, b, x0, W, M)
+                monkeypatch.delenv("MI355_NO_FOLD_DEFL")
+                assert_history(folded, want)
+                assert_history(unfolded, want)
+                assert folded[1] == unfolded[1]
+        # capped solves and the singular-WtAW convention (defcg.jl:273 `WtAW \\ mu`) are the same in the folded form
+        W = np.asfortranarray(Wall[:, :4])
+        assert_history(api.defpcg(S, b, np.zeros(n), W, M, maxit=3), orc.defpcg(So, b, np.zeros(n), W, Mo, maxit=3))
+        Wsing = np.asfortranarray(np.column_stack([W[:, 0], W[:, 1], np.zeros(n)]))      # a zero column: U[3,3] == 0 exactly
+        with pytest.raises(api.SingularException):
+            api.defpcg(S, b, np.zeros(n), Wsing, M)
+        # persistent on-chip pcg
+        for x0 in (np.zeros(n), np.random.default_rng(1).standard_normal(n)):
+            want = orc.pcg(So, b, x0, Mo)
+            monkeypatch.setenv("MI355_RESIDENT", "1")
+            res_ = api.pcg(S, b, x0, M)
+            cap_ = api.pcg(S, b, x0, M, maxit=3)
+            monkeypatch.delenv("MI355_RESIDENT")
+            assert_history(res_, want)
+            assert_history(cap_, orc.pcg(So, b, x0, Mo, maxit=3))
+            assert res_[1] == api.pcg(S, b, x0, M)[1]
+
+
 # ------------------------------------------------------------------ matrix-free operator with the interior CG on the device
 def test_matrix_free_device_interior_cg(pkg, ctx, orc, ragged):
     """`apply_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, ...; reltol)` with `IterativeSolvers.cg` as the interior solve

@@ -241,6 +241,35 @@ int mi_schur_matfree_rhs(mi_op_t op, const double *b_I, const double *b_gamma, d
  * operator's subdomains with its own interior solve; b_I and u_I are concatenations over those subdomains. */
 int mi_schur_matfree_interior_solutions(mi_op_t op, const double *u_gamma, const double *b_I, double *u_I);
 
+/* ---------------------------------------------------------------- set-up of the assembled mode on the device
+ * mi_schur_setup_* — `assemble_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, ...)` (EPDD.jl:667-695): the dense local Schur complements
+ * S_d = A_ΓΓdd - A_IΓdd' A_IIdd^{-1} A_IΓdd of ALL subdomains, symmetrised from the upper triangle as the reference does
+ * (`Symmetric(Array(...))`, :692), and — optionally — the condensed right-hand sides w_d = A_IΓdd' (A_IIdd \ b_Id) that
+ * `get_schur_rhs` subtracts from b_Γ (EPDD.jl:853-861). The reference applies apply_local_schur (interior CG, reltol 1e-9) to
+ * every unit vector; here the interior is eliminated exactly, level by level (block-tridiagonal Cholesky over breadth-first
+ * levels grown from Γ_d; rocBLAS / rocSOLVER for the dense steps) — a documented deviation that only tightens S_d.
+ *   create: the sparsity of the blocks (CSC colptr / rowval as for mi_schur_matfree_device_create), once per mesh / partition
+ *   run   : one realization. ii_val / ig_val / gg_val: the concatenations over the subdomains of the blocks' CSC nzval arrays
+ *           (the layout mi_assembly_run produces and mi_schur_matfree_set_values takes); b_I: concatenated b_Id or NULL.
+ *           Sd receives the concatenated column-major n_Γd x n_Γd blocks, w (may be NULL) the concatenated w_d. Host or
+ *           device pointers per the context's pointer mode; with device pointers the call is asynchronous on the stream.
+ * mi_nn_pinv — `prepare_neumann_neumann_schur_precond(Sd, ...)` (EPDD.jl:1201-1220): ΠS_d = pinv(S_d, rtol) of the symmetric
+ * blocks through their eigen-decomposition (singular values = |eigenvalues|; those <= rtol * the largest are dropped, as
+ * LinearAlgebra.pinv does); rtol <= 0 means sqrt(eps(Float64)), the reference's value.
+ * mi_dense_set_blocks — new blocks (concatenated, column-major) for an existing mi_schur_assembled / mi_nn operator on the same
+ * maps: the per-realization update of S (Example07:180-199) without re-creating the operator. */
+typedef struct mi_setup_s *mi_setup_t;
+int mi_schur_setup_create(mi_ctx_t ctx, int64_t ndom, const int64_t *n_gamma_d, const int64_t *n_i,
+                          const int64_t *const *ii_colptr, const int64_t *const *ii_rowval,
+                          const int64_t *const *ig_colptr, const int64_t *const *ig_rowval,
+                          const int64_t *const *gg_colptr, const int64_t *const *gg_rowval, int index_base,
+                          mi_setup_t *plan);
+int mi_schur_setup_run(mi_setup_t plan, const double *ii_val, const double *ig_val, const double *gg_val,
+                       const double *b_I, double *Sd, double *w);
+int mi_schur_setup_destroy(mi_setup_t plan);
+int mi_nn_pinv(mi_ctx_t ctx, int64_t ndom, const int64_t *n_gamma_d, const double *Sd, double rtol, double *PiSd);
+int mi_dense_set_blocks(mi_op_t op, const double *blocks);
+
 /* ---------------------------------------------------------------- eigCG family and Init-CG (recycling solvers)
  * Reference signatures (RecyclingKrylovSolvers/eigcg.jl:27-33, 143-150; defcg.jl:111-116, 337-343; initcg.jl:28-33,
  * 106-111; callers: Example09_DefPcgMcmcStochasticEllipticPde_Functions.jl:314, 345, 364 on the NN-preconditioned

@@ -76,6 +76,11 @@ SIGNATURES = {
     "mi_assembly_run": [vp, vp, vp],
     "mi_assembly_plan_destroy": [vp],
     "mi_schur_matfree_set_values": [vp, vp, vp, vp],
+    "mi_schur_setup_create": [vp, i64, i64p, i64p, i64pp, i64pp, i64pp, i64pp, i64pp, i64pp, C.c_int, C.POINTER(vp)],
+    "mi_schur_setup_run": [vp, vp, vp, vp, vp, vp, vp],
+    "mi_schur_setup_destroy": [vp],
+    "mi_nn_pinv": [vp, i64, i64p, vp, C.c_double, vp],
+    "mi_dense_set_blocks": [vp, vp],
     "mi_schur_matfree_rhs": [vp, vp, vp, vp],
     "mi_schur_matfree_interior_solutions": [vp, vp, vp, vp],
     "mi_eigcg": [vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],

@@ -538,6 +538,101 @@ class AssemblyPlan:
             pass
 
 
+class SchurSetup:
+    """`assemble_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, ...)` (EPDD.jl:667-695) on the device (`mi_setup_t`): built once from the
+    blocks' sparsity, `run` per realization with the blocks' values — numpy arrays, or torch CUDA tensors as
+    `AssemblyPlan.run` / `.block_values` leave them (nothing visits the host then)."""
+
+    def __init__(self, ctx: Context, A_IIdd, A_IΓdd, A_ΓΓdd, index_base: int = 0):
+        self.ctx = ctx
+        ndom = len(A_IΓdd)
+        self.n_Γd = [int(A.shape[0]) for A in A_ΓΓdd]
+        self.n_Id = [int(A.shape[0]) for A in A_IIdd]
+        nd, ni = _i64(self.n_Γd), _i64(self.n_Id)
+        iip, iii, iiv = _csc_parts(A_IIdd, 0, ndom, index_base)
+        igp, igi, igv = _csc_parts(A_IΓdd, 0, ndom, index_base)
+        ggp, ggi, ggv = _csc_parts(A_ΓΓdd, 0, ndom, index_base)
+        self._vals = (np.concatenate(iiv) if iiv else np.empty(0), np.concatenate(igv), np.concatenate(ggv))
+        h = vp()
+        check(ctx._L.mi_schur_setup_create(ctx._h, i64(ndom), nd.ctypes.data_as(i64p), ni.ctypes.data_as(i64p),
+                                           _ptrs(iip, i64p), _ptrs(iii, i64p), _ptrs(igp, i64p), _ptrs(igi, i64p),
+                                           _ptrs(ggp, i64p), _ptrs(ggi, i64p), C.c_int(index_base), C.byref(h)))
+        self._h = h
+        self.n_S = int(sum(n * n for n in self.n_Γd))
+        self.n_w = int(sum(self.n_Γd))
+
+    def run(self, ii_val=None, ig_val=None, gg_val=None, b_I=None):
+        """-> (Sd, w): the concatenated column-major S_d blocks and (with b_I) the concatenated w_d = A_IΓdd' (A_IIdd \\ b_Id).
+        Values default to those of the matrices given at construction."""
+        ii_val = self._vals[0] if ii_val is None else ii_val
+        ig_val = self._vals[1] if ig_val is None else ig_val
+        gg_val = self._vals[2] if gg_val is None else gg_val
+        self.ctx._mode_for(ii_val, ig_val, gg_val, b_I)
+        k1, p1 = self.ctx._ptr(ii_val)
+        k2, p2 = self.ctx._ptr(ig_val)
+        k3, p3 = self.ctx._ptr(gg_val)
+        k4, p4 = self.ctx._ptr(b_I)
+        if _is_torch(ig_val):
+            import torch
+            Sd = torch.empty(self.n_S, dtype=torch.float64, device=ig_val.device)
+            w = torch.empty(self.n_w, dtype=torch.float64, device=ig_val.device) if b_I is not None else None
+            pS, pw = vp(Sd.data_ptr()), (vp(w.data_ptr()) if w is not None else None)
+        else:
+            Sd = np.empty(self.n_S)
+            w = np.empty(self.n_w) if b_I is not None else None
+            pS, pw = vp(Sd.ctypes.data), (vp(w.ctypes.data) if w is not None else None)
+        check(self.ctx._L.mi_schur_setup_run(self._h, p1, p2, p3, p4, pS, pw))
+        return Sd, w
+
+    def blocks(self, Sd):
+        """The list of n_Γd x n_Γd column-major blocks of a concatenated buffer (views)."""
+        out, off = [], 0
+        for n in self.n_Γd:
+            b = Sd[off:off + n * n]
+            out.append(b.reshape(n, n).T if not _is_torch(Sd) else b.view(n, n).T)
+            off += n * n
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self.ctx._L.mi_schur_setup_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def nn_pinv(ctx: Context, n_Γd, Sd, rtol: float = 0.0):
+    """`prepare_neumann_neumann_schur_precond(Sd, ...)`'s numeric half (EPDD.jl:1211): the concatenated ΠS_d = pinv(S_d,
+    rtol = sqrt(eps)) of the concatenated symmetric blocks, on the device (`mi_nn_pinv`)."""
+    nd = _i64(n_Γd)
+    ctx._mode_for(Sd)
+    k, p = ctx._ptr(Sd, int((nd * nd).sum()))
+    if _is_torch(Sd):
+        import torch
+        out = torch.empty_like(Sd)
+        po = vp(out.data_ptr())
+    else:
+        out = np.empty(k.size)
+        po = vp(out.ctypes.data)
+    check(ctx._L.mi_nn_pinv(ctx._h, i64(nd.size), nd.ctypes.data_as(i64p), p, C.c_double(rtol), po))
+    return out
+
+
+def _set_blocks(self, blocks):
+    """New S_d / ΠS_d (one concatenated column-major buffer, numpy or torch CUDA) on this operator's maps (`mi_dense_set_blocks`)."""
+    self.ctx._mode_for(blocks)
+    k, p = self.ctx._ptr(blocks)
+    check(self.ctx._L.mi_dense_set_blocks(self._h, p))
+
+
+LocalSchurs.set_blocks = _set_blocks
+NeumannNeumannSchurPreconditioner.set_blocks = _set_blocks
+
+
 class GlobalSchur(Operator):
     """`x -> apply_global_schur(A_IId, A_IΓd, A_ΓΓ, x; preconds)` (EPDD.jl:596-625), the closure of Example03:101.
     `interior_solvers[d](rhs)` on the host, or — `interior_solvers=None` — the device CG that restates the reference's

@@ -4,6 +4,7 @@
 #include <tuple>
 
 #include "eig_solvers.hpp"
+#include "setup_dense.hpp"
 
 namespace mi {
 
@@ -758,6 +759,89 @@ int mi_schur_matfree_interior_solutions(mi_op_t op, const double *u_gamma, const
     if (m) m->interior_solutions(ug.dev, bi.dev, out.dev); else gl->interior_solutions(ug.dev, bi.dev, out.dev);
     out.finish();
     MI_HIP(hipStreamSynchronize(c->stream));
+    return MI_OK;
+  });
+}
+
+// ---------------------------------------------------------------- set-up of the assembled mode on the device
+int mi_schur_setup_create(mi_ctx_t ctx, int64_t ndom, const int64_t *n_gamma_d, const int64_t *n_i,
+                          const int64_t *const *ii_colptr, const int64_t *const *ii_rowval, const int64_t *const *ig_colptr,
+                          const int64_t *const *ig_rowval, const int64_t *const *gg_colptr, const int64_t *const *gg_rowval,
+                          int index_base, mi_setup_t *plan) {
+  if (!plan) return fail(MI_ERR_BAD_ARG, "plan is NULL");
+  *plan = nullptr;
+  if (!ctx || ndom <= 0 || !n_gamma_d || !n_i || !ii_colptr || !ii_rowval || !ig_colptr || !ig_rowval || !gg_colptr || !gg_rowval ||
+      (index_base != 0 && index_base != 1))
+    return fail(MI_ERR_BAD_ARG, "mi_schur_setup_create: bad argument");
+  return guarded([&]() -> int {
+    ctx->use();
+    std::unique_ptr<mi_setup_s> p(new mi_setup_s);
+    setup_plan_build(*p, ctx, ndom, n_gamma_d, n_i, ii_colptr, ii_rowval, ig_colptr, ig_rowval, gg_colptr, gg_rowval, index_base);
+    *plan = p.release();
+    return MI_OK;
+  });
+}
+int mi_schur_setup_run(mi_setup_t plan, const double *ii_val, const double *ig_val, const double *gg_val, const double *b_I,
+                       double *Sd, double *w) {
+  if (!plan || !ig_val || !gg_val || !Sd || (plan->n_ii && !ii_val)) return fail(MI_ERR_BAD_ARG, "mi_schur_setup_run: NULL argument");
+  mi_ctx_s *c = plan->ctx;
+  return guarded([&]() -> int {
+    c->use();
+    In a(c, ii_val, (size_t)plan->n_ii, plan->st_ii), b(c, ig_val, (size_t)plan->n_ig, plan->st_ig), g(c, gg_val, (size_t)plan->n_gg, plan->st_gg),
+        bi(c, b_I, b_I ? (size_t)plan->n_bi : 0, plan->st_bi);
+    InOut so(c, Sd, (size_t)plan->n_s, plan->st_S, false), wo(c, w, w ? (size_t)plan->n_w : 0, plan->st_w, false);
+    setup_plan_run(*plan, a.dev, b.dev, g.dev, b_I ? bi.dev : nullptr, so.dev, w ? wo.dev : nullptr);
+    so.finish();
+    wo.finish();
+    if (c->ptr_mode != MI_PTR_DEVICE) {   // host mode is synchronous: a Cholesky that met a non-positive pivot is reported
+      for (auto &l : plan->lanes) {
+        int info[2] = {0, 0};
+        MI_HIP(hipMemcpy(info, l.info.p, sizeof info, hipMemcpyDeviceToHost));
+        if (info[0] || info[1]) return fail(MI_ERR_SINGULAR, "mi_schur_setup_run: an interior block is not positive definite (potrf info %d / %d)", info[0], info[1]);
+      }
+    }
+    return MI_OK;
+  });
+}
+int mi_schur_setup_destroy(mi_setup_t plan) {
+  if (!plan) return MI_OK;
+  return guarded([&]() -> int {
+    plan->ctx->use();
+    (void)hipDeviceSynchronize();
+    delete plan;
+    return MI_OK;
+  });
+}
+int mi_nn_pinv(mi_ctx_t ctx, int64_t ndom, const int64_t *n_gamma_d, const double *Sd, double rtol, double *PiSd) {
+  if (!ctx || ndom <= 0 || !n_gamma_d || !Sd || !PiSd) return fail(MI_ERR_BAD_ARG, "mi_nn_pinv: bad argument");
+  return guarded([&]() -> int {
+    ctx->use();
+    size_t tot = 0;
+    for (int64_t d = 0; d < ndom; ++d) {
+      if (n_gamma_d[d] < 0 || n_gamma_d[d] >= 46000) return fail(MI_ERR_BAD_ARG, "mi_nn_pinv: bad block size");
+      tot += (size_t)n_gamma_d[d] * n_gamma_d[d];
+    }
+    if (rtol <= 0.0) rtol = std::sqrt(2.220446049250313e-16);   // sqrt(eps(Float64)), EPDD.jl:1211
+    DevBuf<double> s1, s2;
+    In si(ctx, Sd, tot, s1);
+    InOut po(ctx, PiSd, tot, s2, false);
+    pinv_blocks(ctx, (int)ndom, n_gamma_d, si.dev, rtol, po.dev);
+    po.finish();
+    return MI_OK;
+  });
+}
+int mi_dense_set_blocks(mi_op_t op, const double *blocks) {
+  DenseBlockOp *dop = op && op->impl ? op->impl->as_dense() : nullptr;
+  if (!dop || !blocks) return fail(MI_ERR_BAD_ARG, "mi_dense_set_blocks: not an assembled-Schur / Neumann-Neumann operator, or NULL blocks");
+  mi_ctx_s *c = dop->ctx;
+  return guarded([&]() -> int {
+    c->use();
+    size_t tot = 0;
+    for (int dl = 0; dl < dop->maps.ndl; ++dl) if (dop->owned_h[dl]) tot += (size_t)dop->maps.nd[dl] * dop->maps.nd[dl];
+    DevBuf<double> st;
+    In bi(c, blocks, tot, st);
+    dop->set_blocks(bi.dev);
+    if (c->ptr_mode != MI_PTR_DEVICE) MI_HIP(hipStreamSynchronize(c->stream));   // the staging buffer goes out of scope
     return MI_OK;
   });
 }

@@ -334,6 +334,7 @@ struct DenseBlockOp : Operator {
   DevBuf<GemvTile> tiles;
   std::vector<long long> moff_h;  // per local subdomain: element offset of its block in M (row-major, ld_h[dl])
   std::vector<int> ld_h;
+  std::vector<char> owned_h;      // per local subdomain: its block is stored on this rank
   int64_t alg_bytes = 0;
   DenseMeta meta{};
 
@@ -396,6 +397,7 @@ struct DenseBlockOp : Operator {
     }
     ntiles = (int)tv.size();
     moff_h = moff; ld_h = ldv;
+    for (int dl = 0; dl < maps.ndl; ++dl) owned_h.push_back(owned(dl) ? 1 : 0);
     M.alloc((size_t)tot);
     // column-major (Julia) -> padded row-major, one block at a time
     for (int dl = 0; dl < maps.ndl; ++dl) {
@@ -454,6 +456,8 @@ struct DenseBlockOp : Operator {
     MI_HIP(hipGetLastError());
   }
   DenseBlockOp *as_dense() override { return this; }
+  // New blocks on the same maps: `src` holds the owned blocks back to back, column-major (device pointer).
+  void set_blocks(const double *src);
   static constexpr int KV = 4;  // columns per pass of apply_multi (4 x 16 KiB of LDS for the operand panels)
   DevBuf<double> yslots_multi;
   void apply_multi(const double *X, int64_t ldx, int k, double *Y, int64_t ldy) override {
@@ -505,6 +509,26 @@ struct DenseBlockOp : Operator {
   void bytes(int64_t *a, int64_t *d) const override { *a = alg_bytes + 8 * n; *d = alg_bytes; }
   void apply_dominant(const double *x) override { gemv(x, nullptr); }
 };
+
+// M[moff + i*ld + j] = src[i + j*n] (column-major block -> padded row-major block)
+__global__ __launch_bounds__(NT) void k_block_to_rowmajor(int n, int ld, const double *__restrict__ src, double *__restrict__ dstm) {
+  const long long tot = (long long)n * n;
+  for (long long e = blockIdx.x * (long long)NT + threadIdx.x; e < tot; e += (long long)gridDim.x * NT) {
+    const int j = (int)(e % n), i = (int)(e / n);   // consecutive threads: consecutive j of one row -> coalesced stores
+    dstm[(long long)i * ld + j] = src[i + (long long)j * n];
+  }
+}
+inline void DenseBlockOp::set_blocks(const double *src) {
+  size_t off = 0;
+  for (int dl = 0; dl < maps.ndl; ++dl) {
+    const int n_d = maps.nd[dl];
+    if (!owned_h[dl] || n_d == 0) continue;
+    hipLaunchKernelGGL(k_block_to_rowmajor, dim3((int)std::max<long long>(1, std::min<long long>(((long long)n_d * n_d + NT - 1) / NT, 4096))),
+                       dim3(NT), 0, ctx->stream, n_d, ld_h[dl], src + off, M.p + moff_h[dl]);
+    off += (size_t)n_d * n_d;
+  }
+  MI_HIP(hipGetLastError());
+}
 
 // ------------------------------------------------------------------ host staging for the interior-solve callback
 struct HostStage {

@@ -25,12 +25,13 @@ import RecyclingKrylovSolvers
 import RecyclingKrylovSolvers: cg, pcg, defcg, defpcg, eigcg, eigpcg, eigdefcg, eigdefpcg, initcg, initpcg
 import Fem
 import Fem: apply_local_schur, apply_local_schurs, apply_global_schur, apply_neumann_neumann_schur,
-            get_schur_rhs, get_subdomain_solutions, NeumannNeumannSchurPreconditioner
+            get_schur_rhs, get_subdomain_solutions, NeumannNeumannSchurPreconditioner,
+            assemble_local_schurs, prepare_neumann_neumann_schur_precond
 
 # new names only (none of them is exported by Fem or RecyclingKrylovSolvers)
 export MiContext, MiOperator, MiPrecond,
        LocalSchurs, LocalSchur, MatrixFreeLocalSchurs, GlobalSchur,
-       AssemblyPlan, assemble!, set_values!
+       AssemblyPlan, assemble!, set_values!, SchurSetup, set_blocks!
 
 const lib = get(ENV, "MI355SCHUR_LIB", "libmi355schur")
 const MI_ERR_SINGULAR = Cint(-3)
@@ -251,6 +252,58 @@ apply_local_schur(S::MiOperator, xd::Vector{Float64}) = S * xd
 apply_local_schurs(S::MiOperator, x::Vector{Float64}) = S * x
 apply_global_schur(S::MiOperator, x::Vector{Float64}) = S * x
 apply_neumann_neumann_schur(Πnn::MiOperator, r::Vector{Float64}) = Πnn * r
+
+# ---------------------------------------------------------------- set-up of the assembled mode on the device
+# Methods added to Fem's `assemble_local_schurs` (EPDD.jl:667-695) and `prepare_neumann_neumann_schur_precond` (:1201-1220):
+# with a MiContext in front the dense S_d come from the device's exact level elimination (mi_schur_setup_*) and the
+# pseudo-inverses from mi_nn_pinv; return types are what LocalSchurs / the device preconditioner take.
+mutable struct SchurSetup
+  h::Ptr{Cvoid}; n_Γd::Vector{Int64}; ctx::MiContext
+end
+function SchurSetup(ctx::MiContext, A_IIdd::Vector{SparseMatrixCSC{Float64,Int}}, A_IΓdd::Vector{SparseMatrixCSC{Float64,Int}},
+                    A_ΓΓdd::Vector{SparseMatrixCSC{Float64,Int}})
+  ndom = length(A_IΓdd)
+  nd = Int64[A.n for A in A_ΓΓdd]; ni = Int64[A.n for A in A_IIdd]
+  iip, iii, _ = csc_parts(A_IIdd); igp, igi, _ = csc_parts(A_IΓdd); ggp, ggi, _ = csc_parts(A_ΓΓdd)
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve iip iii igp igi ggp ggi begin
+    check(ccall((:mi_schur_setup_create, lib), Cint,
+                (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}},
+                 Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Cint, Ref{Ptr{Cvoid}}),
+                ctx.h, ndom, nd, ni, ptrs(iip), ptrs(iii), ptrs(igp), ptrs(igi), ptrs(ggp), ptrs(ggi), 1, r))
+  end
+  p = SchurSetup(r[], nd, ctx)
+  finalizer(q -> ccall((:mi_schur_setup_destroy, lib), Cint, (Ptr{Cvoid},), q.h), p)
+end
+"""`assemble_local_schurs(plan, A_IIdd, A_IΓdd, A_ΓΓdd[, b_Id])`: one realization on a plan built once for the sparsity; returns
+the dense S_d (and, with b_Id, the condensed right-hand sides A_IΓdd' (A_IIdd \\ b_Id) of `get_schur_rhs`, EPDD.jl:853-861)."""
+function assemble_local_schurs(p::SchurSetup, A_IIdd, A_IΓdd, A_ΓΓdd, b_Id=nothing)
+  ii = reduce(vcat, [A.nzval for A in A_IIdd]); ig = reduce(vcat, [A.nzval for A in A_IΓdd]); gg = reduce(vcat, [A.nzval for A in A_ΓΓdd])
+  Sd = Vector{Float64}(undef, sum(p.n_Γd .^ 2)); w = Vector{Float64}(undef, sum(p.n_Γd))
+  bI = b_Id === nothing ? C_NULL : reduce(vcat, b_Id)
+  check(ccall((:mi_schur_setup_run, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+              p.h, ii, ig, gg, bI, Sd, b_Id === nothing ? C_NULL : w))
+  ends = cumsum(p.n_Γd .^ 2)
+  S = [reshape(Sd[(e - n * n + 1):e], n, n) for (e, n) in zip(ends, p.n_Γd)]
+  b_Id === nothing && return S
+  we = cumsum(p.n_Γd)
+  return S, [w[(e - n + 1):e] for (e, n) in zip(we, p.n_Γd)]
+end
+assemble_local_schurs(ctx::MiContext, A_IIdd, A_IΓdd, A_ΓΓdd) = assemble_local_schurs(SchurSetup(ctx, A_IIdd, A_IΓdd, A_ΓΓdd), A_IIdd, A_IΓdd, A_ΓΓdd)
+"""`prepare_neumann_neumann_schur_precond(ctx, Sd, ind_Γd_Γ2l, node_Γ_cnt)`: ΠS_d = pinv(S_d, rtol = sqrt(eps)) on the device
+(EPDD.jl:1211) and the device preconditioner built from them."""
+function prepare_neumann_neumann_schur_precond(ctx::MiContext, Sd::Vector{Matrix{Float64}}, ind_Γd_Γ2l::Vector{Dict{Int,Int}},
+                                               node_Γ_cnt::Vector{Int})
+  nd = Int64[size(S, 1) for S in Sd]
+  cat = reduce(vcat, [vec(S) for S in Sd]); out = similar(cat)
+  check(ccall((:mi_nn_pinv, lib), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}, Float64, Ptr{Float64}), ctx.h, length(Sd), nd, cat, 0.0, out))
+  ends = cumsum(nd .^ 2)
+  ΠSd = [reshape(out[(e - n * n + 1):e], n, n) for (e, n) in zip(ends, nd)]
+  NeumannNeumannSchurPreconditioner(ctx, ΠSd, ind_Γd_Γ2l, node_Γ_cnt)
+end
+"""New S_d / ΠS_d on an existing device operator (same maps): Example07's per-realization update without re-creating it."""
+set_blocks!(op::MiOperator, blocks::Vector{Matrix{Float64}}) =
+  check(ccall((:mi_dense_set_blocks, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), op.h, reduce(vcat, [vec(B) for B in blocks])))
 
 # ---------------------------------------------------------------- solver drop-ins (whole loop on the GPU)
 # Same positional order, keyword and 3-tuple return as RecyclingKrylovSolvers (cg.jl:14,67; defcg.jl:24,242).

@@ -82,7 +82,8 @@ def test_shim_extends_and_never_shadows_the_reference():
     for need in ("cg", "pcg", "defcg", "defpcg", "eigcg", "eigpcg", "eigdefcg", "eigdefpcg", "initcg", "initpcg"):
         assert need in defined and need in rks
     for need in ("apply_local_schur", "apply_local_schurs", "apply_global_schur", "apply_neumann_neumann_schur",
-                 "get_schur_rhs", "get_subdomain_solutions", "NeumannNeumannSchurPreconditioner"):
+                 "get_schur_rhs", "get_subdomain_solutions", "NeumannNeumannSchurPreconditioner", "assemble_local_schurs",
+                 "prepare_neumann_neumann_schur_precond"):
         assert need in defined and need in fem
     clash = _exports(s) & (RKS_EXPORTS | FEM_EXPORTS)
     assert not clash, f"the shim exports names the reference exports too: {sorted(clash)}"
@@ -90,8 +91,8 @@ def test_shim_extends_and_never_shadows_the_reference():
 
 # ---------------------------------------------------------------- ccall signatures vs the header
 C2J = [
-    (r"^(mi_ctx_t|mi_op_t|mi_event_t|mi_plan_t|void \*|mi_interior_solve_fn|const void \*)$", {"Ptr{Cvoid}"}),
-    (r"^(mi_ctx_t|mi_op_t|mi_event_t|mi_plan_t|void \*) ?\*$", {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"}),
+    (r"^(mi_ctx_t|mi_op_t|mi_event_t|mi_plan_t|mi_setup_t|void \*|mi_interior_solve_fn|const void \*)$", {"Ptr{Cvoid}"}),
+    (r"^(mi_ctx_t|mi_op_t|mi_event_t|mi_plan_t|mi_setup_t|void \*) ?\*$", {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"}),
     (r"^int64_t$", {"Int64"}),
     (r"^int$", {"Cint"}),
     (r"^double$", {"Float64"}),
@@ -173,5 +174,6 @@ def test_every_ccall_matches_the_c_prototype():
                  "mi_schur_matfree_create", "mi_schur_matfree_device_create", "mi_schur_global_create",
                  "mi_schur_global_device_create", "mi_cg", "mi_pcg", "mi_defcg", "mi_defpcg", "mi_eigcg", "mi_eigpcg",
                  "mi_eigdefcg", "mi_eigdefpcg", "mi_initcg", "mi_initpcg", "mi_assembly_plan_create", "mi_assembly_run",
-                 "mi_schur_matfree_set_values", "mi_schur_matfree_rhs", "mi_schur_matfree_interior_solutions"):
+                 "mi_schur_matfree_set_values", "mi_schur_matfree_rhs", "mi_schur_matfree_interior_solutions",
+                 "mi_schur_setup_create", "mi_schur_setup_run", "mi_nn_pinv", "mi_dense_set_blocks"):
         assert need in seen, f"{need} is not bound by the shim"

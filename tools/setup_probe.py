@@ -33,8 +33,6 @@ for lanes in (1,):
     bI = torch.from_numpy(np.concatenate(P.b_Id)).cuda()
     t0 = time.perf_counter(); setup.run(*vals, bI); ctx.synchronize()
     print(f"  first (eager) run {time.perf_counter() - t0:.2f} s", flush=True)
-    t0 = time.perf_counter(); setup.run(*vals, bI); ctx.synchronize()
-    print(f"  second run (graph capture + instantiate + replay) {time.perf_counter() - t0:.2f} s", flush=True)
     ts = []
     for _ in range(3):
         t0 = time.perf_counter()

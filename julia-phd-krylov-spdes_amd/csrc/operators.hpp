@@ -398,7 +398,10 @@ struct DenseBlockOp : Operator {
     ntiles = (int)tv.size();
     moff_h = moff; ld_h = ldv;
     for (int dl = 0; dl < maps.ndl; ++dl) owned_h.push_back(owned(dl) ? 1 : 0);
-    M.alloc((size_t)tot);
+    // (+ one zeroed panel behind the last block: the persistent kernel reads whole 128-double groups of a row without
+    // clamping, so a read may run past a row's end — into the next row, or into this tail — and meets a zero operand there)
+    M.alloc((size_t)tot + GEMV_PANEL);
+    MI_HIP(hipMemset(M.p + tot, 0, sizeof(double) * GEMV_PANEL));
     // column-major (Julia) -> padded row-major, one block at a time
     for (int dl = 0; dl < maps.ndl; ++dl) {
       if (!owned(dl)) continue;

@@ -39,12 +39,11 @@ struct GraphKey {
 // of them fit into registers / LDS, and the hand-off buffers of the grid barrier.
 struct ResidentPlan {
   int G = 0, max_rows = 0;
-  double resident_frac = 0.0;   // share of the matrix elements held in registers or LDS
+  double resident_frac = 0.0;   // share of the matrix elements held in registers or LDS or passing through the streaming slot
   bool usable = false;
-  unsigned epoch = 0;
+  unsigned long long epoch = 16;   // records are zero-initialised: epochs start above 0
   DevBuf<ResTile> tiles;
-  DevBuf<double> part;
-  DevBuf<unsigned> flags;
+  DevBuf<ResRec> recs;
   DevBuf<int> abort;
   std::vector<ResTile> tiles_h;
 
@@ -53,7 +52,7 @@ struct ResidentPlan {
     MI_HIP(hipGetDeviceProperties(&prop, c->device));
     G = env_int("MI355_RES_G", prop.multiProcessorCount);
     const int ndl = A.maps.ndl;
-    if (G < 1 || ndl < 1 || ndl > G || G > 4 * RES_NTH) return;
+    if (G < 1 || ndl < 1 || ndl > G || G > RES_NTH) return;   // one published record per thread when polling
     // workgroups per subdomain in proportion to its elements, at least one each, G in all
     std::vector<double> wgt(ndl);
     double tot = 0.0;
@@ -94,17 +93,16 @@ struct ResidentPlan {
       const long long fixed = (long long)res_lds_fixed(t.U, max_rows), rowb = (long long)t.U * 128 * 8;
       if (fixed > RES_LDS_BYTES) return;
       const int cap = (int)((RES_LDS_BYTES - fixed) / rowb);
-      const int needS = std::max(0, t.nrows - RES_WAVES * res_slots_S(t.U)), needP = std::max(0, t.nrows - RES_WAVES * res_slots_P(t.U));
+      const int needS = std::max(0, t.nrows - res_reg_rows_S(t.U)), needP = std::max(0, t.nrows - res_reg_rows_P(t.U));
       t.ldsS = std::min(needS, cap / 2);
       t.ldsP = std::min(needP, cap - t.ldsS);
       t.ldsS = std::min(needS, cap - t.ldsP);
-      res_el += (double)(std::min(t.nrows, RES_WAVES * res_slots_S(t.U) + t.ldsS) + std::min(t.nrows, RES_WAVES * res_slots_P(t.U) + t.ldsP)) * t.ld;
+      res_el += (double)(std::min(t.nrows, res_reg_rows_S(t.U) + t.ldsS) + std::min(t.nrows, res_reg_rows_P(t.U) + t.ldsP)) * t.ld;
       all_el += 2.0 * t.nrows * t.ld;
     }
     resident_frac = all_el > 0 ? res_el / all_el : 0.0;
     tiles.upload(tiles_h, c->stream);
-    part.alloc((size_t)4 * G); part.zero(c->stream);
-    flags.alloc((size_t)G); flags.zero(c->stream);
+    recs.alloc((size_t)4 * G); recs.zero(c->stream);
     abort.alloc(1); abort.zero(c->stream);
     static bool attr_set = false;
     if (!attr_set) {
@@ -114,9 +112,9 @@ struct ResidentPlan {
     MI_HIP(hipStreamSynchronize(c->stream));
     usable = resident_frac * 100.0 >= env_int("MI355_RES_MIN_PCT", 50);
   }
-  void reset(hipStream_t s) {  // after an aborted launch: the flags are in an unknown state
-    flags.zero(s); abort.zero(s);
-    epoch = 0;
+  void reset(hipStream_t s) {  // after an aborted launch
+    abort.zero(s);
+    epoch += 1u << 20;
   }
 };
 
@@ -613,7 +611,7 @@ struct Krylov {
       ResArgs ra{};
       ra.MS = Ad->M.p; ra.MP = Md->M.p; ra.tiles = rp->tiles.p; ra.gidx = Ad->maps.gidx.p; ra.cnt = Md->cnt.p;
       ra.tgt = Ad->maps.tgt.p; ra.jrank = Ad->maps.jrank.p; ra.conS = Ad->fold_con(); ra.conP = Md->fold_con();
-      ra.part = rp->part.p; ra.flags = rp->flags.p; ra.abort = rp->abort.p; ra.st = ws.st; ra.res_norm = ws.res_norm.p;
+      ra.recs = rp->recs.p; ra.abort = rp->abort.p; ra.st = ws.st; ra.res_norm = ws.res_norm.p;
       ra.x = ws.x; ra.b = ws.b; ra.epoch0 = rp->epoch; ra.W = Ad->maps.slot_width; ra.G = rp->G; ra.max_rows = rp->max_rows;
       DevBuf<long long> dbg;
       const bool debug = env_int("MI355_RES_DEBUG", 0) != 0;
@@ -627,13 +625,13 @@ struct Krylov {
         MI_HIP(hipMemcpy(h.data(), dbg.p, 512 * sizeof(long long), hipMemcpyDeviceToHost));
         const ResTile &tt = rp->tiles_h[ra.dbg_wg];
         std::fprintf(stderr, "[resident] wg %d: n=%d ld=%d rows=%d U=%d regS=%d regP=%d ldsS=%d ldsP=%d resident_frac=%.3f\n", ra.dbg_wg, tt.n,
-                     tt.ld, tt.nrows, tt.U, RES_WAVES * res_slots_S(tt.U), RES_WAVES * res_slots_P(tt.U), tt.ldsS, tt.ldsP, rp->resident_frac);
+                     tt.ld, tt.nrows, tt.U, RES_WAVES * res_slots_S(tt.U), RES_WAVES * res_slots_P(tt.U), tt.ldsS, tt.ldsP, rp->resident_frac);   // (+8 rows per operator in the streaming slot)
         std::fprintf(stderr, "[resident] stamps (us since start):");
         for (int k = 0; k < 512 && h[k]; ++k) std::fprintf(stderr, "%s%.2f", (k >= 5 && (k - 5) % 8 == 0) ? "\n  " : " ", (h[k] - h[0]) * 0.01);
         std::fprintf(stderr, "\n");
       }
       if (ws.flags[0].done) {
-        rp->epoch += (unsigned)(2 * ws.flags[0].it + 4);
+        rp->epoch += (unsigned long long)(2 * ws.flags[0].it + 4);
         ran_resident = true;
         use_graph = false;
       } else {

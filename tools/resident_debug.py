@@ -19,6 +19,7 @@ ctx = api.Context(0)
 n = P.sub.n_Γ
 S = api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt)
 M = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt)
+os.environ["MI355_RESIDENT"] = "1"
 for k in range(3):
     api.pcg(S, P.b_schur, np.zeros(n), M)
 for wg in (0, 100, 255):

@@ -36,7 +36,7 @@ def run(P, label, reps):
     xo, ito, reso = orc.pcg(So, P.b_schur, np.zeros(n), Mo)
     out = {}
     for mode in ("resident", "folded"):
-        os.environ["MI355_NO_RESIDENT"] = "0" if mode == "resident" else "1"
+        os.environ["MI355_RESIDENT"] = "1" if mode == "resident" else "0"
         x, it, res = api.pcg(S, P.b_schur, np.zeros(n), M)
         dev = np.max(np.abs(res[:min(it, ito)] - reso[:min(it, ito)]) / reso[:min(it, ito)])
         b = torch.from_numpy(P.b_schur).cuda()
@@ -53,13 +53,13 @@ def run(P, label, reps):
         print(f"{label:28s} {mode:9s}: it={it} (oracle {ito})  max rel dev of res_norm {dev:.2e}  |x-xo|/|xo| "
               f"{np.linalg.norm(x - xo) / np.linalg.norm(xo):.2e}  {dt * 1e6:8.1f} us/solve  {(it - 1) / dt:9.0f} it/s", flush=True)
     # a non-zero initial guess and a capped solve
-    os.environ["MI355_NO_RESIDENT"] = "0"
+    os.environ["MI355_RESIDENT"] = "1"
     x0 = np.random.default_rng(1).standard_normal(n)
     g = api.pcg(S, P.b_schur, x0, M); w = orc.pcg(So, P.b_schur, x0, Mo)
     print(f"{'':28s} x0 != 0  : it={g[1]} (oracle {w[1]})  |x-xo|/|xo| {np.linalg.norm(g[0] - w[0]) / np.linalg.norm(w[0]):.2e}", flush=True)
     g = api.pcg(S, P.b_schur, np.zeros(n), M, maxit=4); w = orc.pcg(So, P.b_schur, np.zeros(n), Mo, maxit=4)
     print(f"{'':28s} maxit=4  : it={g[1]} (oracle {w[1]})  |x-xo|/|xo| {np.linalg.norm(g[0] - w[0]) / np.linalg.norm(w[0]):.2e}", flush=True)
-    os.environ.pop("MI355_NO_RESIDENT")
+    os.environ.pop("MI355_RESIDENT")
 
 
 one = lambda x, y: 1.0 + 0 * x      # noqa: E731

@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--seed", type=int, default=481456)
     ap.add_argument("--out", default="")
     ap.add_argument("--device-assembly", action="store_true")
+    ap.add_argument("--device-setup", action="store_true",
+                    help="with --device-assembly: S_d, the condensed rhs and NN_t on the device too (mi_schur_setup_run, mi_nn_pinv, "
+                         "mi_dense_set_blocks): nothing of a realization's set-up runs on the host")
     ap.add_argument("--recycle", action="store_true")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -67,25 +70,48 @@ def main():
     if args.device_assembly:
         plan = fem.make_assembly_plan(mesh.cells, mesh.points, P0.epart, sub, f, uexact)
         dev_plan = api.AssemblyPlan(ctx, plan)
+    setup = S_dev = NN_dev = None
+    if args.device_setup:
+        if not args.device_assembly:
+            raise SystemExit("--device-setup needs --device-assembly")
+        import torch
+        setup = api.SchurSetup(ctx, P0.A_IIdd, P0.A_IΓdd, P0.A_ΓΓdd)
+        S_dev = api.LocalSchurs(ctx, P0.Sd, sub.gather_idx, sub.node_Γ_cnt)
+        NN_dev = api.NeumannNeumannSchurPreconditioner(ctx, P0.ΠSd, sub.gather_idx, sub.node_Γ_cnt)
     iters_0, iters_t, iters_def, iters_rec = [], [], [], []
     W_rec, nvec, spdim = None, int(1.25 * ndom), 3 * ndom
     for ireal in range(rank, args.nreals, world):
-        blocks = plan.blocks(dev_plan.run(np.exp(gs[ireal]))) if plan else None                       # :162-171 on the GPU
-        P = fem.build_schur_problem(args.N, args.px, args.py, np.exp(gs[ireal]), f, uexact, mesh=mesh,
-                                    partition=(P0.epart, None), blocks=blocks, sub=sub)          # :162-199
-        S = api.LocalSchurs(ctx, P.Sd, sub.gather_idx, sub.node_Γ_cnt)
-        ΠSnn_t = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, sub.gather_idx, sub.node_Γ_cnt)
+        if setup is not None:
+            # the whole realization on the device: element loop -> block values -> S_d, w_d -> operators refilled
+            vals = dev_plan.run(torch.from_numpy(np.exp(gs[ireal])).cuda())
+            ii, ig, gg, bI, bΓ = dev_plan.block_values(vals)
+            Sd, w = setup.run(ii, ig, gg, bI)                                                          # :180-187
+            S_dev.set_blocks(Sd)
+            NN_dev.set_blocks(api.nn_pinv(ctx, sub.n_Γd, Sd))                                          # :190-199
+            ctx.synchronize()
+            b_schur, wh, off = bΓ.cpu().numpy().copy(), w.cpu().numpy(), 0
+            for d in range(ndom):                                                                      # get_schur_rhs, EPDD.jl:853-861
+                b_schur[sub.gather_idx[d]] -= wh[off:off + sub.n_Γd[d]]
+                off += sub.n_Γd[d]
+            S, ΠSnn_t = S_dev, NN_dev
+        else:
+            blocks = plan.blocks(dev_plan.run(np.exp(gs[ireal]))) if plan else None                   # :162-171 on the GPU
+            P = fem.build_schur_problem(args.N, args.px, args.py, np.exp(gs[ireal]), f, uexact, mesh=mesh,
+                                        partition=(P0.epart, None), blocks=blocks, sub=sub)      # :162-199
+            S = api.LocalSchurs(ctx, P.Sd, sub.gather_idx, sub.node_Γ_cnt)
+            ΠSnn_t = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, sub.gather_idx, sub.node_Γ_cnt)
+            b_schur = P.b_schur
         x0 = np.zeros(n_Γ)
-        iters_0.append(api.pcg(S, P.b_schur, x0, ΠSnn_0)[1])                                          # :273
-        iters_t.append(api.pcg(S, P.b_schur, x0, ΠSnn_t)[1])                                          # :277
-        iters_def.append(api.defpcg(S, P.b_schur, x0, W_0, ΠSnn_0)[1])
+        iters_0.append(api.pcg(S, b_schur, x0, ΠSnn_0)[1])                                            # :273
+        iters_t.append(api.pcg(S, b_schur, x0, ΠSnn_t)[1])                                            # :277
+        iters_def.append(api.defpcg(S, b_schur, x0, W_0, ΠSnn_0)[1])
         rec = ""
         if args.recycle:
             try:
                 if W_rec is None:
-                    _, it, _, W_rec = api.eigpcg(S, P.b_schur, x0, ΠSnn_0, nvec, spdim)
+                    _, it, _, W_rec = api.eigpcg(S, b_schur, x0, ΠSnn_0, nvec, spdim)
                 else:
-                    _, it, _, W_rec = api.eigdefpcg(S, P.b_schur, x0, ΠSnn_0, W_rec, spdim)
+                    _, it, _, W_rec = api.eigdefpcg(S, b_schur, x0, ΠSnn_0, W_rec, spdim)
                 iters_rec.append(it)
                 rec = f"  eig(def)pcg(W recycled, NN_0) it={it}"
             except (api.BoundsError, api.SingularException) as e:          # Example09:355-375: status = -1

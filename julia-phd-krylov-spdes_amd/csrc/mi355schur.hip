@@ -4,7 +4,7 @@
 #include <tuple>
 
 #include "eig_solvers.hpp"
-#include "setup_dense.hpp"
+#include "setup_gj.hpp"
 
 namespace mi {
 
@@ -790,7 +790,8 @@ int mi_schur_setup_run(mi_setup_t plan, const double *ii_val, const double *ig_v
     In a(c, ii_val, (size_t)plan->n_ii, plan->st_ii), b(c, ig_val, (size_t)plan->n_ig, plan->st_ig), g(c, gg_val, (size_t)plan->n_gg, plan->st_gg),
         bi(c, b_I, b_I ? (size_t)plan->n_bi : 0, plan->st_bi);
     InOut so(c, Sd, (size_t)plan->n_s, plan->st_S, false), wo(c, w, w ? (size_t)plan->n_w : 0, plan->st_w, false);
-    setup_plan_run(*plan, a.dev, b.dev, g.dev, b_I ? bi.dev : nullptr, so.dev, w ? wo.dev : nullptr);
+    if (plan->lanes.empty()) gj_run(*plan, a.dev, b.dev, g.dev, b_I ? bi.dev : nullptr, so.dev, w ? wo.dev : nullptr);
+    else setup_plan_run(*plan, a.dev, b.dev, g.dev, b_I ? bi.dev : nullptr, so.dev, w ? wo.dev : nullptr);   // MI355_SETUP_LIB=1
     so.finish();
     wo.finish();
     if (c->ptr_mode != MI_PTR_DEVICE) {   // host mode is synchronous: a Cholesky that met a non-positive pivot is reported

@@ -118,9 +118,13 @@ struct SetupDom {
   long long b_e0 = 0, b_e1 = 0, g_e0 = 0, g_e1 = 0;
   long long ii_val_off = 0, ig_val_off = 0, gg_val_off = 0, bi_off = 0, s_off = 0, w_off = 0;
   int max_lev = 0;
+  // CSC form of the coupling blocks (hand-written elimination): for level k the columns of C_k = A_{k+1,k}, as offsets into
+  // the plan-wide arrays c_ptr / c_row / c_src; [nlev - 1] entries; then B = A_IΓ[L_0, :] by Γ_d column
+  std::vector<int> cptr_off;
+  int bptr_off = 0;
 };
 
-struct mi_setup_s_impl;
+struct GjState;
 }  // namespace mi
 
 struct mi_setup_s {
@@ -138,7 +142,12 @@ struct mi_setup_s {
   };
   std::vector<Lane> lanes;
   mi::DevBuf<double> st_ii, st_ig, st_gg, st_bi, st_S, st_w;   // staging for host-pointer calls
-  ~mi_setup_s() {
+  // hand-written elimination (block Gauss-Jordan, batched over the subdomains, replayed from a hipGraph)
+  std::vector<int> c_ptr_h, c_row_h, c_src_h;
+  mi::DevBuf<int> c_ptr, c_row, c_src;
+  std::unique_ptr<mi::GjState> gj;
+  ~mi_setup_s();
+  void release_lanes() {
     for (auto &l : lanes) {
       if (l.h) (void)mi::RocLa::get().destroy_handle(l.h);
       if (l.s) (void)hipStreamDestroy(l.s);
@@ -216,6 +225,19 @@ inline void setup_plan_build(mi_setup_s &P, mi_ctx_s *c, int64_t ndom, const int
       for (auto &p : v) { src.push_back(p.first); dst.push_back(p.second); }
       return e0;
     };
+    // CSC (by column position in the level) of every coupling block, for the pick kernels
+    for (int l = 0; l + 1 < D.nlev; ++l) {
+      const int nr = D.lev_off[l + 2] - D.lev_off[l + 1], nc = D.lev_off[l + 1] - D.lev_off[l];
+      std::vector<std::vector<std::pair<int, int>>> cols(nc);
+      for (auto &e : El[l]) cols[e.second / nr].push_back({e.second % nr, e.first});
+      D.cptr_off.push_back((int)P.c_ptr_h.size());
+      for (int j = 0; j < nc; ++j) {
+        P.c_ptr_h.push_back((int)P.c_row_h.size());
+        std::sort(cols[j].begin(), cols[j].end());
+        for (auto &e : cols[j]) { P.c_row_h.push_back(e.first); P.c_src_h.push_back(e.second); }
+      }
+      P.c_ptr_h.push_back((int)P.c_row_h.size());
+    }
     for (int l = 0; l < D.nlev; ++l) D.d_e0.push_back(flush(Dl[l]));
     D.d_e0.push_back((long long)src.size());
     for (int l = 0; l + 1 < D.nlev; ++l) D.e_e0.push_back(flush(El[l]));
@@ -229,6 +251,14 @@ inline void setup_plan_build(mi_setup_s &P, mi_ctx_s *c, int64_t ndom, const int
         src.push_back((int)(P.n_ig + k)); dst.push_back(pos[row] + col * std::max(n0, 1));
       }
     D.b_e1 = (long long)src.size();
+    D.bptr_off = (int)P.c_ptr_h.size();
+    for (int col = 0; col < ng; ++col) {
+      P.c_ptr_h.push_back((int)P.c_row_h.size());
+      for (int64_t k = gp[col] - base; k < gp[col + 1] - base; ++k) {
+        P.c_row_h.push_back(pos[(int)(gx[k] - base)]); P.c_src_h.push_back((int)(P.n_ig + k));
+      }
+    }
+    P.c_ptr_h.push_back((int)P.c_row_h.size());
     D.g_e0 = (long long)src.size();
     for (int col = 0; col < ng; ++col)
       for (int64_t k = sp[col] - base; k < sp[col + 1] - base; ++k) {
@@ -248,6 +278,8 @@ inline void setup_plan_build(mi_setup_s &P, mi_ctx_s *c, int64_t ndom, const int
   if (src.size() >= (size_t)INT32_MAX) raise(MI_ERR_BAD_ARG, "setup plan: too many entries");
   hipStream_t s = c->stream;
   P.src.upload(src, s); P.dst.upload(dst, s); P.perm.upload(perm_all, s);
+  P.c_ptr.upload(P.c_ptr_h, s); P.c_row.upload(P.c_row_h, s); P.c_src.upload(P.c_src_h, s);
+  if (!env_int("MI355_SETUP_LIB", 0)) return;   // the library path (rocBLAS / rocSOLVER chains) is the cross-check, on request
   RocLa &la = RocLa::get();
   // One chain at a time by default: with several rocSOLVER/rocBLAS handles running potrf / trsm chains concurrently on
   // different streams some S_d came out wrong at the 1e-7 level (tools/setup_probe.py, config 3), with one stream every

@@ -1,0 +1,394 @@
+// The level elimination of setup_dense.hpp with kernels of this library only, batched over the subdomains and replayed
+// from one hipGraph per realization (the library path issues ~250 levels x dozens of small rocSOLVER / rocBLAS kernels
+// per subdomain from the host: ~3 s per realization at config 3, bound by the host's launch rate; rocSOLVER cannot be
+// captured into a graph).
+//
+// Formulation. With Z_k = T_k^{-1} kept explicitly (dense, symmetric) the recursion of setup_dense.hpp reads
+//     T_k = A_kk - C_k' Z_{k+1} C_k,     g_k = b_k - C_k' (Z_{k+1} g_{k+1}),     Z_k = T_k^{-1},
+//     S_d = A_ΓΓ - B' Z_0 B,             w_d = B' (Z_0 g_0),
+// where C_k = A_{k+1,k} and B = A_IΓ[L_0, :] are SPARSE (a P1 node has <= 3-4 neighbours in the adjacent level), so every
+// entry of C' Z C is a sum of a dozen picked entries of Z ("pick" kernels, one thread per entry) and the only dense
+// O(n^3) work per level is the inversion of the SPD matrix T_k: an in-place-style block Gauss-Jordan inversion without
+// pivoting (block size 32; the k-th pivot block of an SPD matrix is its k-th Schur complement, SPD again), 2 launches
+// per block step: the 32 x 32 pivot block is inverted by one workgroup in LDS, then one launch updates the whole
+// matrix from the previous copy (ping-pong buffers: no launch reads what it writes) —
+//     row panel   P A_Kj,   column panel   -A_iK P,   trailing   A_ij - A_iK (P A_Kj),   pivot block   P.
+// All subdomains advance together (grid.z), aligned so that they reach level 0 in the same step. The launch sequence
+// depends only on the plan: it is captured once and replayed per realization on plan-owned buffers.
+#pragma once
+#include "setup_dense.hpp"
+
+namespace mi {
+
+constexpr int GJ_B = 32;    // pivot block
+constexpr int GJ_T = 64;    // tile of the update launch (256 threads, 4 x 4 outputs each)
+
+struct GjStep {             // one per (step, subdomain); n0 == 0: the subdomain is not active in this step
+  int n1, n0;               // size of the deeper level (dimension of Z_in; 0 at the subdomain's first step) and of this level
+  int zin;                  // which ping-pong buffer holds Z_in (0 / 1)
+  int cptr;                 // offset of C_k's column pointers (n0 + 1 entries)
+  long long d_e0, d_e1;     // entry list of A_kk
+  int b_off;                // offset of this level's nodes in `perm` (gather of b_k)
+  int nb;                   // GJ block steps of this level = ceil(n0 / GJ_B)
+};
+struct GjDom {              // per subdomain
+  double *T, *Z[2], *y, *g[2], *P;
+  int ng, n_last, zfin;     // n_Γd; size of level 0; buffer holding Z_0
+  int bptr;                 // offset of B's column pointers (ng + 1 entries)
+  long long g_e0, g_e1;     // entry list of A_ΓΓ
+  long long s_off, w_off;
+  int nlev;
+};
+
+struct GjState {
+  int nsteps = 0, ndom = 0, nmax = 0, ngmax = 0;
+  std::vector<GjStep> steps_h;
+  std::vector<GjDom> dom_h;
+  std::vector<int> nb_step;          // GJ block steps to launch per step (max over the active subdomains)
+  DevBuf<GjStep> steps;
+  DevBuf<GjDom> doms;
+  DevBuf<double> pool;               // all work buffers
+  DevBuf<double> in_ii, in_ig, in_gg, in_bi, out_S, out_w;   // plan-owned I/O of the captured graph
+  hipGraphExec_t graph[2] = {nullptr, nullptr};               // without / with right-hand side
+  bool graph_failed = false;
+  ~GjState() {
+    for (auto &g : graph) if (g) (void)hipGraphExecDestroy(g);
+  }
+};
+
+#pragma clang fp contract(fast)
+
+// T[i,j] = -(C' Z C)[i,j]  (0 at a subdomain's first step); the entries of A_kk are added by k_gj_scatter
+__global__ __launch_bounds__(256) void k_gj_pick(int step, int ndom, const GjStep *__restrict__ steps, const GjDom *__restrict__ doms,
+                                                 const int *__restrict__ c_ptr, const int *__restrict__ c_row,
+                                                 const int *__restrict__ c_src, const double *__restrict__ ii_val) {
+  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
+  const int n0 = st.n0;
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (i >= n0 || j >= n0) return;
+  const GjDom dm = doms[blockIdx.z];
+  double acc = 0.0;
+  if (st.n1 > 0) {
+    const double *Z = dm.Z[st.zin];
+    const int *cp = c_ptr + st.cptr;
+    const int ia = cp[i], ib = cp[i + 1], ja = cp[j], jb = cp[j + 1];
+    for (int p = ia; p < ib; ++p) {
+      const double ci = ii_val[c_src[p]];
+      const double *zr = Z + (size_t)c_row[p];            // Z[a, :] read as Z[a + b*n1] (symmetric)
+      double s = 0.0;
+      for (int q = ja; q < jb; ++q) s += zr[(size_t)c_row[q] * st.n1] * ii_val[c_src[q]];
+      acc += ci * s;
+    }
+  }
+  dm.T[i + (size_t)j * n0] = -acc;
+}
+__global__ __launch_bounds__(256) void k_gj_scatter(int step, int ndom, const GjStep *__restrict__ steps, const GjDom *__restrict__ doms,
+                                                    const int *__restrict__ src, const int *__restrict__ dst,
+                                                    const double *__restrict__ ii_val) {
+  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
+  if (st.n0 == 0) return;
+  double *T = doms[blockIdx.z].T;
+  for (long long e = st.d_e0 + blockIdx.x * 256ll + threadIdx.x; e < st.d_e1; e += (long long)gridDim.x * 256) T[dst[e]] += ii_val[src[e]];
+}
+// y = Z_in g_in (Z symmetric, column-major: consecutive threads read consecutive rows)
+__global__ __launch_bounds__(256) void k_gj_zg(int step, int ndom, const GjStep *__restrict__ steps, const GjDom *__restrict__ doms) {
+  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (st.n0 == 0 || a >= st.n1) return;
+  const GjDom dm = doms[blockIdx.z];
+  const double *Z = dm.Z[st.zin], *g = dm.g[(step + 1) & 1];
+  double s = 0.0;
+  for (int b = 0; b < st.n1; ++b) s += Z[a + (size_t)b * st.n1] * g[b];
+  dm.y[a] = s;
+}
+// g_k = b_k - C_k' y
+__global__ __launch_bounds__(256) void k_gj_g(int step, int ndom, const GjStep *__restrict__ steps, const GjDom *__restrict__ doms,
+                                              const int *__restrict__ c_ptr, const int *__restrict__ c_row, const int *__restrict__ c_src,
+                                              const double *__restrict__ ii_val, const int *__restrict__ perm, const double *__restrict__ bI) {
+  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= st.n0) return;
+  const GjDom dm = doms[blockIdx.z];
+  double v = bI[perm[st.b_off + j]];
+  if (st.n1 > 0) {
+    const int *cp = c_ptr + st.cptr;
+    double s = 0.0;
+    for (int p = cp[j]; p < cp[j + 1]; ++p) s += ii_val[c_src[p]] * dm.y[c_row[p]];
+    v -= s;
+  }
+  dm.g[step & 1][j] = v;
+}
+
+// ---- block Gauss-Jordan inversion of T (n0 x n0, SPD), block step kb: source = T (kb == 0) or Z[kb & 1], destination Z[(kb + 1) & 1]
+__device__ __forceinline__ const double *gj_src(const GjDom &dm, int kb) { return kb == 0 ? dm.T : dm.Z[kb & 1]; }
+// P = (pivot block)^{-1}, one workgroup per subdomain, unblocked Gauss-Jordan in LDS
+__global__ __launch_bounds__(256) void k_gj_pivot(int step, int kb, int ndom, const GjStep *__restrict__ steps,
+                                                  const GjDom *__restrict__ doms) {
+  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
+  if (kb >= st.nb) return;
+  const GjDom dm = doms[blockIdx.z];
+  const int n = st.n0, k0 = kb * GJ_B, bs = min(GJ_B, n - k0);
+  const double *A = gj_src(dm, kb);
+  __shared__ double a[GJ_B][GJ_B + 1];
+  for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) {
+    const int r = e % GJ_B, c = e / GJ_B;
+    a[r][c] = (r < bs && c < bs) ? A[(k0 + r) + (size_t)(k0 + c) * n] : (r == c ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  for (int p = 0; p < bs; ++p) {
+    const double piv = 1.0 / a[p][p];
+    __syncthreads();
+    if ((int)threadIdx.x < GJ_B) a[p][threadIdx.x] = (int)threadIdx.x == p ? piv : a[p][threadIdx.x] * piv;   // row p
+    __syncthreads();
+    for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) {
+      const int r = e % GJ_B, c = e / GJ_B;
+      if (r != p && c != p) a[r][c] -= a[r][p] * a[p][c];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < GJ_B && (int)threadIdx.x != p) a[threadIdx.x][p] = -a[threadIdx.x][p] * piv;      // column p
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) dm.P[e] = a[e % GJ_B][e / GJ_B];             // column-major 32 x 32
+}
+// one 64 x 64 tile of the updated matrix from the previous copy
+__global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, const GjStep *__restrict__ steps,
+                                                   const GjDom *__restrict__ doms) {
+  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
+  const int n = st.n0;
+  if (kb >= st.nb || (int)blockIdx.x * GJ_T >= n || (int)blockIdx.y * GJ_T >= n) return;
+  const GjDom dm = doms[blockIdx.z];
+  const int k0 = kb * GJ_B, bs = min(GJ_B, n - k0);
+  const double *A = gj_src(dm, kb);
+  double *O = dm.Z[(kb + 1) & 1];
+  const int i0 = blockIdx.x * GJ_T, j0 = blockIdx.y * GJ_T;
+  __shared__ double Pm[GJ_B][GJ_B + 1];        // P[r][c]
+  __shared__ double R[GJ_B][GJ_T + 1];         // R = P * A[K, J]   (32 x 64)
+  __shared__ double Cc[GJ_T][GJ_B + 1];        // A[I, K]           (64 x 32)
+  __shared__ double Ak[GJ_B][GJ_T + 1];        // A[K, J] staged for R
+  for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) Pm[e % GJ_B][e / GJ_B] = dm.P[e];
+  for (int e = threadIdx.x; e < GJ_B * GJ_T; e += 256) {
+    const int t = e % GJ_B, c = e / GJ_B;        // A[k0 + t, j0 + c]: consecutive threads walk down a column
+    Ak[t][c] = (t < bs && j0 + c < n) ? A[(k0 + t) + (size_t)(j0 + c) * n] : 0.0;
+  }
+  for (int e = threadIdx.x; e < GJ_T * GJ_B; e += 256) {
+    const int r = e % GJ_T, t = e / GJ_T;        // A[i0 + r, k0 + t]
+    Cc[r][t] = (t < bs && i0 + r < n) ? A[(i0 + r) + (size_t)(k0 + t) * n] : 0.0;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < GJ_B * GJ_T; e += 256) {
+    const int t = e % GJ_B, c = e / GJ_B;
+    double s = 0.0;
+#pragma unroll 8
+    for (int u = 0; u < GJ_B; ++u) s += Pm[t][u] * Ak[u][c];
+    R[t][c] = s;
+  }
+  __syncthreads();
+  const int tr = (threadIdx.x & 15) * 4, tc = (threadIdx.x >> 4) * 4;   // this thread's 4 x 4 outputs
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    const int j = j0 + tc + cc;
+    if (j >= n) continue;
+    const bool jk = j >= k0 && j < k0 + bs;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int i = i0 + tr + rr;
+      if (i >= n) continue;
+      const bool ik = i >= k0 && i < k0 + bs;
+      double v;
+      if (ik && jk) v = Pm[i - k0][j - k0];
+      else if (ik) v = R[i - k0][tc + cc];                                   // (P A_Kj)[i - k0, j]
+      else if (jk) {                                                         // -(A_iK P)[i, j - k0]
+        double s = 0.0;
+        for (int u = 0; u < GJ_B; ++u) s += Cc[tr + rr][u] * Pm[u][j - k0];
+        v = -s;
+      } else {
+        double s = 0.0;
+#pragma unroll 8
+        for (int u = 0; u < GJ_B; ++u) s += Cc[tr + rr][u] * R[u][tc + cc];
+        v = A[i + (size_t)j * n] - s;
+      }
+      O[i + (size_t)j * n] = v;
+    }
+  }
+}
+// ---- the end of a subdomain's chain: S (upper triangle mirrored) = A_ΓΓ - B' Z_0 B; w = B' (Z_0 g_0)
+__global__ __launch_bounds__(256) void k_gj_final_pick(int ndom, const GjDom *__restrict__ doms, const int *__restrict__ c_ptr,
+                                                       const int *__restrict__ c_row, const int *__restrict__ c_src,
+                                                       const double *__restrict__ ig_val) {
+  const GjDom dm = doms[blockIdx.z];
+  const int ng = dm.ng;
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (i >= ng || j >= ng) return;
+  double acc = 0.0;
+  if (dm.n_last > 0) {
+    const double *Z = dm.Z[dm.zfin];
+    const int *cp = c_ptr + dm.bptr;
+    for (int p = cp[i]; p < cp[i + 1]; ++p) {
+      const double ci = ig_val[c_src[p]];
+      const double *zr = Z + (size_t)c_row[p];
+      double s = 0.0;
+      for (int q = cp[j]; q < cp[j + 1]; ++q) s += zr[(size_t)c_row[q] * dm.n_last] * ig_val[c_src[q]];
+      acc += ci * s;
+    }
+  }
+  dm.T[i + (size_t)j * ng] = -acc;
+}
+__global__ __launch_bounds__(256) void k_gj_final_scatter(int ndom, const GjDom *__restrict__ doms, const int *__restrict__ src,
+                                                          const int *__restrict__ dst, const double *__restrict__ gg_val) {
+  const GjDom dm = doms[blockIdx.z];
+  for (long long e = dm.g_e0 + blockIdx.x * 256ll + threadIdx.x; e < dm.g_e1; e += (long long)gridDim.x * 256) dm.T[dst[e]] += gg_val[src[e]];
+}
+__global__ __launch_bounds__(256) void k_gj_final_sym(int ndom, const GjDom *__restrict__ doms, double *__restrict__ Sd) {
+  const GjDom dm = doms[blockIdx.z];
+  const int ng = dm.ng;
+  const long long tot = (long long)ng * ng;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+    const int i = (int)(e % ng), j = (int)(e / ng);
+    Sd[dm.s_off + e] = i <= j ? dm.T[i + (size_t)j * ng] : dm.T[j + (size_t)i * ng];   // `Symmetric(Array(...))`, EPDD.jl:692
+  }
+}
+__global__ __launch_bounds__(256) void k_gj_final_zg(int ndom, int last_step, const GjDom *__restrict__ doms) {
+  const GjDom dm = doms[blockIdx.z];
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= dm.n_last) return;
+  const double *Z = dm.Z[dm.zfin], *g = dm.g[last_step & 1];
+  double s = 0.0;
+  for (int b = 0; b < dm.n_last; ++b) s += Z[a + (size_t)b * dm.n_last] * g[b];
+  dm.y[a] = s;
+}
+__global__ __launch_bounds__(256) void k_gj_final_w(int ndom, const GjDom *__restrict__ doms, const int *__restrict__ c_ptr,
+                                                    const int *__restrict__ c_row, const int *__restrict__ c_src,
+                                                    const double *__restrict__ ig_val, double *__restrict__ w) {
+  const GjDom dm = doms[blockIdx.z];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= dm.ng) return;
+  double s = 0.0;
+  if (dm.n_last > 0) {
+    const int *cp = c_ptr + dm.bptr;
+    for (int p = cp[j]; p < cp[j + 1]; ++p) s += ig_val[c_src[p]] * dm.y[c_row[p]];
+  }
+  w[dm.w_off + j] = s;
+}
+#pragma clang fp contract(off)
+
+inline void gj_build(mi_setup_s &P) {
+  std::unique_ptr<GjState> G(new GjState);
+  G->ndom = P.ndom;
+  int smax = 0;
+  for (auto &D : P.dom) { smax = std::max(smax, D.nlev); G->nmax = std::max(G->nmax, D.max_lev); G->ngmax = std::max(G->ngmax, D.n_g); }
+  G->nsteps = smax;
+  G->steps_h.assign((size_t)std::max(1, smax) * P.ndom, GjStep{});
+  G->nb_step.assign(std::max(1, smax), 0);
+  // work buffers: T also receives the final n_Γd x n_Γd pick
+  size_t tot = 0;
+  std::vector<size_t> off_T(P.ndom), off_Z0(P.ndom), off_Z1(P.ndom), off_y(P.ndom), off_g0(P.ndom), off_g1(P.ndom), off_P(P.ndom);
+  for (int d = 0; d < P.ndom; ++d) {
+    const SetupDom &D = P.dom[d];
+    const size_t nm = (size_t)std::max(1, D.max_lev), nt = (size_t)std::max<int>(std::max(1, D.max_lev), D.n_g);
+    auto take = [&](size_t cnt) { const size_t o = tot; tot += (cnt + 31) / 32 * 32; return o; };
+    off_T[d] = take(nt * nt); off_Z0[d] = take(nm * nm); off_Z1[d] = take(nm * nm);
+    off_y[d] = take(nm); off_g0[d] = take(nm); off_g1[d] = take(nm); off_P[d] = take(GJ_B * GJ_B);
+  }
+  G->pool.alloc(tot + 32);
+  MI_HIP(hipMemset(G->pool.p, 0, sizeof(double) * (tot + 32)));
+  G->dom_h.resize(P.ndom);
+  for (int d = 0; d < P.ndom; ++d) {
+    const SetupDom &D = P.dom[d];
+    GjDom &q = G->dom_h[d];
+    q.T = G->pool.p + off_T[d]; q.Z[0] = G->pool.p + off_Z0[d]; q.Z[1] = G->pool.p + off_Z1[d];
+    q.y = G->pool.p + off_y[d]; q.g[0] = G->pool.p + off_g0[d]; q.g[1] = G->pool.p + off_g1[d]; q.P = G->pool.p + off_P[d];
+    q.ng = D.n_g; q.nlev = D.nlev; q.bptr = D.bptr_off; q.g_e0 = D.g_e0; q.g_e1 = D.g_e1; q.s_off = D.s_off; q.w_off = D.w_off;
+    q.n_last = D.nlev ? D.lev_off[1] - D.lev_off[0] : 0;
+    q.zfin = 0;
+    int zin = 0;
+    for (int k = D.nlev - 1; k >= 0; --k) {           // level k is handled in step smax - 1 - k
+      const int step = smax - 1 - k;
+      GjStep &st = G->steps_h[(size_t)step * P.ndom + d];
+      st.n0 = D.lev_off[k + 1] - D.lev_off[k];
+      st.n1 = k + 1 < D.nlev ? D.lev_off[k + 2] - D.lev_off[k + 1] : 0;
+      st.zin = zin;
+      st.cptr = k + 1 < D.nlev ? D.cptr_off[k] : 0;
+      st.d_e0 = D.d_e0[k]; st.d_e1 = D.d_e0[k + 1];
+      st.b_off = (int)D.bi_off + D.lev_off[k];
+      st.nb = (st.n0 + GJ_B - 1) / GJ_B;
+      zin = st.nb & 1;                                 // block step kb writes Z[(kb + 1) & 1]: the inverse ends in Z[nb & 1]
+      G->nb_step[step] = std::max(G->nb_step[step], st.nb);
+    }
+    q.zfin = zin;
+  }
+  hipStream_t s = P.ctx->stream;
+  G->steps.upload(G->steps_h, s);
+  G->doms.upload(G->dom_h, s);
+  G->in_ii.alloc((size_t)P.n_ii + 1); G->in_ig.alloc((size_t)P.n_ig + 1); G->in_gg.alloc((size_t)P.n_gg + 1);
+  G->in_bi.alloc((size_t)P.n_bi + 1); G->out_S.alloc((size_t)P.n_s + 1); G->out_w.alloc((size_t)P.n_w + 1);
+  P.gj = std::move(G);
+}
+
+// enqueue the whole elimination on `s` (plain launches: capturable)
+inline void gj_enqueue(mi_setup_s &P, hipStream_t s, const double *ii, const double *ig, const double *gg, const double *bI, double *Sd,
+                       double *w) {
+  GjState &G = *P.gj;
+  const int nd = P.ndom;
+  const GjStep *st = G.steps.p;
+  const GjDom *dm = G.doms.p;
+  auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+  const int nm = std::max(1, G.nmax);
+  for (int step = 0; step < G.nsteps; ++step) {
+    if (bI && step > 0) hipLaunchKernelGGL(k_gj_zg, dim3(cdiv(nm, 256), 1, nd), dim3(256), 0, s, step, nd, st, dm);
+    hipLaunchKernelGGL(k_gj_pick, dim3(cdiv(nm, 16), cdiv(nm, 16), nd), dim3(256), 0, s, step, nd, st, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ii);
+    hipLaunchKernelGGL(k_gj_scatter, dim3(8, 1, nd), dim3(256), 0, s, step, nd, st, dm, P.src.p, P.dst.p, ii);
+    if (bI) hipLaunchKernelGGL(k_gj_g, dim3(cdiv(nm, 256), 1, nd), dim3(256), 0, s, step, nd, st, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ii, P.perm.p, bI);
+    for (int kb = 0; kb < G.nb_step[step]; ++kb) {
+      hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nd), dim3(256), 0, s, step, kb, nd, st, dm);
+      hipLaunchKernelGGL(k_gj_update, dim3(cdiv(nm, GJ_T), cdiv(nm, GJ_T), nd), dim3(256), 0, s, step, kb, nd, st, dm);
+    }
+  }
+  const int ngm = std::max(1, G.ngmax);
+  hipLaunchKernelGGL(k_gj_final_pick, dim3(cdiv(ngm, 16), cdiv(ngm, 16), nd), dim3(256), 0, s, nd, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ig);
+  hipLaunchKernelGGL(k_gj_final_scatter, dim3(8, 1, nd), dim3(256), 0, s, nd, dm, P.src.p, P.dst.p, gg);
+  hipLaunchKernelGGL(k_gj_final_sym, dim3(256, 1, nd), dim3(256), 0, s, nd, dm, Sd);
+  if (bI && w) {
+    hipLaunchKernelGGL(k_gj_final_zg, dim3(cdiv(nm, 256), 1, nd), dim3(256), 0, s, nd, G.nsteps - 1, dm);
+    hipLaunchKernelGGL(k_gj_final_w, dim3(cdiv(ngm, 256), 1, nd), dim3(256), 0, s, nd, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ig, w);
+  }
+  MI_HIP(hipGetLastError());
+}
+
+inline void gj_run(mi_setup_s &P, const double *ii_val, const double *ig_val, const double *gg_val, const double *bI, double *Sd, double *w) {
+  if (!P.gj) gj_build(P);
+  GjState &G = *P.gj;
+  hipStream_t s = P.ctx->stream;
+  const bool rhs = bI != nullptr && w != nullptr;
+  auto cp = [&](double *dst, const double *src, long long cnt) {
+    if (cnt > 0) MI_HIP(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToDevice, s));
+  };
+  if (G.graph_failed || env_int("MI355_SETUP_NO_GRAPH", 0)) { gj_enqueue(P, s, ii_val, ig_val, gg_val, rhs ? bI : nullptr, Sd, w); return; }
+  hipGraphExec_t &ex = G.graph[rhs ? 1 : 0];
+  if (!ex) {
+    hipGraph_t gr = nullptr;
+    bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      try {
+        gj_enqueue(P, s, G.in_ii.p, G.in_ig.p, G.in_gg.p, rhs ? G.in_bi.p : nullptr, G.out_S.p, rhs ? G.out_w.p : nullptr);
+      } catch (const Error &) { ok = false; }
+      if (hipStreamEndCapture(s, &gr) != hipSuccess) ok = false;
+    }
+    if (ok && gr) ok = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) == hipSuccess;
+    if (gr) (void)hipGraphDestroy(gr);
+    if (!ok) {
+      (void)hipGetLastError();
+      ex = nullptr; G.graph_failed = true;
+      gj_enqueue(P, s, ii_val, ig_val, gg_val, rhs ? bI : nullptr, Sd, w);
+      return;
+    }
+  }
+  cp(G.in_ii.p, ii_val, P.n_ii); cp(G.in_ig.p, ig_val, P.n_ig); cp(G.in_gg.p, gg_val, P.n_gg);
+  if (rhs) cp(G.in_bi.p, bI, P.n_bi);
+  MI_HIP(hipGraphLaunch(ex, s));
+  cp(Sd, G.out_S.p, P.n_s);
+  if (rhs) cp(w, G.out_w.p, P.n_w);
+}
+
+}  // namespace mi
+
+inline mi_setup_s::~mi_setup_s() { release_lanes(); }

@@ -45,6 +45,7 @@ struct GjState {
   std::vector<GjStep> steps_h;
   std::vector<GjDom> dom_h;
   std::vector<int> nb_step;          // GJ block steps to launch per step (max over the active subdomains)
+  std::vector<int> n_step;           // largest level of the step (grid sizes)
   DevBuf<GjStep> steps;
   DevBuf<GjDom> doms;
   DevBuf<double> pool;               // all work buffers
@@ -90,16 +91,33 @@ __global__ __launch_bounds__(256) void k_gj_scatter(int step, int ndom, const Gj
   double *T = doms[blockIdx.z].T;
   for (long long e = st.d_e0 + blockIdx.x * 256ll + threadIdx.x; e < st.d_e1; e += (long long)gridDim.x * 256) T[dst[e]] += ii_val[src[e]];
 }
-// y = Z_in g_in (Z symmetric, column-major: consecutive threads read consecutive rows)
+// y = Z g for 64 rows per workgroup (Z symmetric, column-major: a wave reads 64 consecutive rows of one column); the
+// columns are dealt to the four waves and the partial sums meet in LDS
+__device__ __forceinline__ void gj_gemv64(const double *__restrict__ Z, int n, const double *__restrict__ g, double *__restrict__ y) {
+  __shared__ double part[4][64];
+  const int r = blockIdx.x * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6;
+  double s = 0.0;
+  if (r < n)
+    for (int b0 = wv; b0 < n; b0 += 16) {      // four columns in flight per thread
+      double z[4], gg[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int b = b0 + 4 * k;
+        z[k] = b < n ? Z[r + (size_t)b * n] : 0.0;
+        gg[k] = b < n ? g[b] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += z[k] * gg[k];
+    }
+  part[wv][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && r < n) y[r] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
 __global__ __launch_bounds__(256) void k_gj_zg(int step, int ndom, const GjStep *__restrict__ steps, const GjDom *__restrict__ doms) {
   const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
-  const int a = blockIdx.x * 256 + threadIdx.x;
-  if (st.n0 == 0 || a >= st.n1) return;
+  if (st.n0 == 0 || (int)blockIdx.x * 64 >= st.n1) return;
   const GjDom dm = doms[blockIdx.z];
-  const double *Z = dm.Z[st.zin], *g = dm.g[(step + 1) & 1];
-  double s = 0.0;
-  for (int b = 0; b < st.n1; ++b) s += Z[a + (size_t)b * st.n1] * g[b];
-  dm.y[a] = s;
+  gj_gemv64(dm.Z[st.zin], st.n1, dm.g[(step + 1) & 1], dm.y);
 }
 // g_k = b_k - C_k' y
 __global__ __launch_bounds__(256) void k_gj_g(int step, int ndom, const GjStep *__restrict__ steps, const GjDom *__restrict__ doms,
@@ -121,36 +139,45 @@ __global__ __launch_bounds__(256) void k_gj_g(int step, int ndom, const GjStep *
 
 // ---- block Gauss-Jordan inversion of T (n0 x n0, SPD), block step kb: source = T (kb == 0) or Z[kb & 1], destination Z[(kb + 1) & 1]
 __device__ __forceinline__ const double *gj_src(const GjDom &dm, int kb) { return kb == 0 ? dm.T : dm.Z[kb & 1]; }
-// P = (pivot block)^{-1}, one workgroup per subdomain, unblocked Gauss-Jordan in LDS
-__global__ __launch_bounds__(256) void k_gj_pivot(int step, int kb, int ndom, const GjStep *__restrict__ steps,
-                                                  const GjDom *__restrict__ doms) {
+// P = (pivot block)^{-1}: ONE wave per subdomain, lane r holds row r of the block in registers; a Gauss-Jordan step
+// broadcasts the scaled pivot row with v_readlane (no LDS round trips, no barriers in the 32-step dependency chain).
+__global__ __launch_bounds__(64) void k_gj_pivot(int step, int kb, int ndom, const GjStep *__restrict__ steps,
+                                                 const GjDom *__restrict__ doms) {
   const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
   if (kb >= st.nb) return;
   const GjDom dm = doms[blockIdx.z];
   const int n = st.n0, k0 = kb * GJ_B, bs = min(GJ_B, n - k0);
   const double *A = gj_src(dm, kb);
-  __shared__ double a[GJ_B][GJ_B + 1];
-  for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) {
-    const int r = e % GJ_B, c = e / GJ_B;
-    a[r][c] = (r < bs && c < bs) ? A[(k0 + r) + (size_t)(k0 + c) * n] : (r == c ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  for (int p = 0; p < bs; ++p) {
-    const double piv = 1.0 / a[p][p];
-    __syncthreads();
-    if ((int)threadIdx.x < GJ_B) a[p][threadIdx.x] = (int)threadIdx.x == p ? piv : a[p][threadIdx.x] * piv;   // row p
-    __syncthreads();
-    for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) {
-      const int r = e % GJ_B, c = e / GJ_B;
-      if (r != p && c != p) a[r][c] -= a[r][p] * a[p][c];
+  const int r = threadIdx.x & 31;                      // lanes 32..63 mirror lanes 0..31 (results of the lower half are stored)
+  double row[GJ_B];
+#pragma unroll
+  for (int c = 0; c < GJ_B; ++c) row[c] = (r < bs && c < bs) ? A[(k0 + r) + (size_t)(k0 + c) * n] : (r == c ? 1.0 : 0.0);
+#pragma unroll
+  for (int p = 0; p < GJ_B; ++p) {
+    const double piv = 1.0 / lane_read(row[p], p);
+    if (r == p) {
+#pragma unroll
+      for (int c = 0; c < GJ_B; ++c) row[c] = c == p ? piv : row[c] * piv;
     }
-    __syncthreads();
-    if ((int)threadIdx.x < GJ_B && (int)threadIdx.x != p) a[threadIdx.x][p] = -a[threadIdx.x][p] * piv;      // column p
-    __syncthreads();
+    const double f = row[p];
+#pragma unroll
+    for (int c = 0; c < GJ_B; ++c) {
+      const double rp = lane_read(row[c], p);          // the (scaled) pivot row, uniform
+      if (r != p && c != p) row[c] -= f * rp;
+    }
+    if (r != p) row[p] = -f * piv;
   }
-  for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) dm.P[e] = a[e % GJ_B][e / GJ_B];             // column-major 32 x 32
+  if (threadIdx.x < GJ_B) {
+#pragma unroll
+    for (int c = 0; c < GJ_B; ++c) dm.P[r + c * GJ_B] = row[c];                  // column-major 32 x 32
+  }
 }
-// one 64 x 64 tile of the updated matrix from the previous copy
+// one 64 x 64 tile of the updated matrix from the previous copy, on the fp64 matrix cores (v_mfma_f64_16x16x4_f64:
+// A[l & 15][k = l >> 4], B[k = l >> 4][l & 15], D: col = l & 15, row = (l >> 4) + 4 reg). R = P A[K, J] (32 x 64) first, then
+// the trailing update computed TRANSPOSED — the instruction's row index runs over the tile's columns j, its column index
+// over the tile's rows i — so that a lane's four results sit in 16-lane groups of consecutive i: loads and stores of the
+// column-major matrix are 128-byte segments. Wave v owns rows 16 v .. 16 v + 15 of the tile.
+typedef double gj_d4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, const GjStep *__restrict__ steps,
                                                    const GjDom *__restrict__ doms) {
   const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
@@ -161,55 +188,69 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   const double *A = gj_src(dm, kb);
   double *O = dm.Z[(kb + 1) & 1];
   const int i0 = blockIdx.x * GJ_T, j0 = blockIdx.y * GJ_T;
-  __shared__ double Pm[GJ_B][GJ_B + 1];        // P[r][c]
-  __shared__ double R[GJ_B][GJ_T + 1];         // R = P * A[K, J]   (32 x 64)
-  __shared__ double Cc[GJ_T][GJ_B + 1];        // A[I, K]           (64 x 32)
-  __shared__ double Ak[GJ_B][GJ_T + 1];        // A[K, J] staged for R
+  __shared__ double Pm[GJ_B][GJ_B + 1];          // P[r][c]
+  __shared__ double R[GJ_B][GJ_T + 1];           // R = P * A[K, J]   (32 x 64)
+  __shared__ double Cc[GJ_T][GJ_B + 1];          // A[I, K]           (64 x 32)
+  __shared__ double Ak[GJ_B][GJ_T + 1];          // A[K, J]
+  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = l & 15, lk = l >> 4;
   for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) Pm[e % GJ_B][e / GJ_B] = dm.P[e];
   for (int e = threadIdx.x; e < GJ_B * GJ_T; e += 256) {
     const int t = e % GJ_B, c = e / GJ_B;        // A[k0 + t, j0 + c]: consecutive threads walk down a column
     Ak[t][c] = (t < bs && j0 + c < n) ? A[(k0 + t) + (size_t)(j0 + c) * n] : 0.0;
   }
-  for (int e = threadIdx.x; e < GJ_T * GJ_B; e += 256) {
-    const int r = e % GJ_T, t = e / GJ_T;        // A[i0 + r, k0 + t]
-    Cc[r][t] = (t < bs && i0 + r < n) ? A[(i0 + r) + (size_t)(k0 + t) * n] : 0.0;
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < GJ_B * GJ_T; e += 256) {
-    const int t = e % GJ_B, c = e / GJ_B;
-    double s = 0.0;
-#pragma unroll 8
-    for (int u = 0; u < GJ_B; ++u) s += Pm[t][u] * Ak[u][c];
-    R[t][c] = s;
-  }
-  __syncthreads();
-  const int tr = (threadIdx.x & 15) * 4, tc = (threadIdx.x >> 4) * 4;   // this thread's 4 x 4 outputs
+  for (int t = wv; t < GJ_B; t += 4)             // A[i0 + l, k0 + t]
+    Cc[l][t] = (t < bs && i0 + l < n) ? A[(i0 + l) + (size_t)(k0 + t) * n] : 0.0;
+  // the old entries this lane will update (D layout of the transposed product): i = i0 + 16 wv + lc, j = j0 + 16 jt + lk + 4 v
+  const int i = i0 + 16 * wv + lc;
+  gj_d4 acc[4];
 #pragma unroll
-  for (int cc = 0; cc < 4; ++cc) {
-    const int j = j0 + tc + cc;
-    if (j >= n) continue;
-    const bool jk = j >= k0 && j < k0 + bs;
+  for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int i = i0 + tr + rr;
-      if (i >= n) continue;
-      const bool ik = i >= k0 && i < k0 + bs;
-      double v;
-      if (ik && jk) v = Pm[i - k0][j - k0];
-      else if (ik) v = R[i - k0][tc + cc];                                   // (P A_Kj)[i - k0, j]
-      else if (jk) {                                                         // -(A_iK P)[i, j - k0]
-        double s = 0.0;
-        for (int u = 0; u < GJ_B; ++u) s += Cc[tr + rr][u] * Pm[u][j - k0];
-        v = -s;
-      } else {
-        double s = 0.0;
-#pragma unroll 8
-        for (int u = 0; u < GJ_B; ++u) s += Cc[tr + rr][u] * R[u][tc + cc];
-        v = A[i + (size_t)j * n] - s;
-      }
-      O[i + (size_t)j * n] = v;
+    for (int v = 0; v < 4; ++v) {
+      const int j = j0 + 16 * jt + lk + 4 * v;
+      acc[jt][v] = (i < n && j < n) ? A[i + (size_t)j * n] : 0.0;
+    }
+  __syncthreads();
+  {  // R = Pm * Ak: 2 x 4 blocks of 16 x 16, two per wave (t-block = wv & 1, j-blocks 2 (wv >> 1) and + 1)
+    const int tb = wv & 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int jbk = 2 * (wv >> 1) + q;
+      gj_d4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < GJ_B; kk += 4)
+        d = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[16 * tb + lc][kk + lk], Ak[kk + lk][16 * jbk + lc], d, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) R[16 * tb + lk + 4 * v][16 * jbk + lc] = d[v];
     }
   }
+  __syncthreads();
+  // acc[jt] (rows j, cols i) -= R[K, J_jt]' * Cc[I, K]'  ==  (A_ij - A_iK (P A_Kj))'
+#pragma unroll
+  for (int kk = 0; kk < GJ_B; kk += 4) {
+    const double bneg = -Cc[16 * wv + lc][kk + lk];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(R[kk + lk][16 * jt + lc], bneg, acc[jt], 0, 0, 0);
+  }
+  if (i >= n) return;
+  const bool ik = i >= k0 && i < k0 + bs;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int jl = 16 * jt + lk + 4 * v, j = j0 + jl;
+      if (j >= n) continue;
+      const bool jk = j >= k0 && j < k0 + bs;
+      double val = acc[jt][v];                                                 // A_ij - A_iK (P A_Kj)
+      if (ik && jk) val = Pm[i - k0][j - k0];
+      else if (ik) val = R[i - k0][jl];                                        // (P A_Kj)[i - k0, j]
+      else if (jk) {                                                           // -(A_iK P)[i, j - k0]
+        double s2 = 0.0;
+        for (int u = 0; u < GJ_B; ++u) s2 += Cc[16 * wv + lc][u] * Pm[u][j - k0];
+        val = -s2;
+      }
+      O[i + (size_t)j * n] = val;
+    }
 }
 // ---- the end of a subdomain's chain: S (upper triangle mirrored) = A_ΓΓ - B' Z_0 B; w = B' (Z_0 g_0)
 __global__ __launch_bounds__(256) void k_gj_final_pick(int ndom, const GjDom *__restrict__ doms, const int *__restrict__ c_ptr,
@@ -249,12 +290,8 @@ __global__ __launch_bounds__(256) void k_gj_final_sym(int ndom, const GjDom *__r
 }
 __global__ __launch_bounds__(256) void k_gj_final_zg(int ndom, int last_step, const GjDom *__restrict__ doms) {
   const GjDom dm = doms[blockIdx.z];
-  const int a = blockIdx.x * 256 + threadIdx.x;
-  if (a >= dm.n_last) return;
-  const double *Z = dm.Z[dm.zfin], *g = dm.g[last_step & 1];
-  double s = 0.0;
-  for (int b = 0; b < dm.n_last; ++b) s += Z[a + (size_t)b * dm.n_last] * g[b];
-  dm.y[a] = s;
+  if ((int)blockIdx.x * 64 >= dm.n_last) return;
+  gj_gemv64(dm.Z[dm.zfin], dm.n_last, dm.g[last_step & 1], dm.y);
 }
 __global__ __launch_bounds__(256) void k_gj_final_w(int ndom, const GjDom *__restrict__ doms, const int *__restrict__ c_ptr,
                                                     const int *__restrict__ c_row, const int *__restrict__ c_src,
@@ -279,6 +316,7 @@ inline void gj_build(mi_setup_s &P) {
   G->nsteps = smax;
   G->steps_h.assign((size_t)std::max(1, smax) * P.ndom, GjStep{});
   G->nb_step.assign(std::max(1, smax), 0);
+  G->n_step.assign(std::max(1, smax), 1);
   // work buffers: T also receives the final n_Γd x n_Γd pick
   size_t tot = 0;
   std::vector<size_t> off_T(P.ndom), off_Z0(P.ndom), off_Z1(P.ndom), off_y(P.ndom), off_g0(P.ndom), off_g1(P.ndom), off_P(P.ndom);
@@ -313,6 +351,7 @@ inline void gj_build(mi_setup_s &P) {
       st.nb = (st.n0 + GJ_B - 1) / GJ_B;
       zin = st.nb & 1;                                 // block step kb writes Z[(kb + 1) & 1]: the inverse ends in Z[nb & 1]
       G->nb_step[step] = std::max(G->nb_step[step], st.nb);
+      G->n_step[step] = std::max(G->n_step[step], std::max(st.n0, st.n1));
     }
     q.zfin = zin;
   }
@@ -332,23 +371,25 @@ inline void gj_enqueue(mi_setup_s &P, hipStream_t s, const double *ii, const dou
   const GjStep *st = G.steps.p;
   const GjDom *dm = G.doms.p;
   auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
-  const int nm = std::max(1, G.nmax);
+  int nm = std::max(1, G.nmax);
   for (int step = 0; step < G.nsteps; ++step) {
-    if (bI && step > 0) hipLaunchKernelGGL(k_gj_zg, dim3(cdiv(nm, 256), 1, nd), dim3(256), 0, s, step, nd, st, dm);
+    nm = G.n_step[step];   // grids cover the largest level of this step only
+    if (bI && step > 0) hipLaunchKernelGGL(k_gj_zg, dim3(cdiv(nm, 64), 1, nd), dim3(256), 0, s, step, nd, st, dm);
     hipLaunchKernelGGL(k_gj_pick, dim3(cdiv(nm, 16), cdiv(nm, 16), nd), dim3(256), 0, s, step, nd, st, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ii);
     hipLaunchKernelGGL(k_gj_scatter, dim3(8, 1, nd), dim3(256), 0, s, step, nd, st, dm, P.src.p, P.dst.p, ii);
     if (bI) hipLaunchKernelGGL(k_gj_g, dim3(cdiv(nm, 256), 1, nd), dim3(256), 0, s, step, nd, st, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ii, P.perm.p, bI);
     for (int kb = 0; kb < G.nb_step[step]; ++kb) {
-      hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nd), dim3(256), 0, s, step, kb, nd, st, dm);
+      hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nd), dim3(64), 0, s, step, kb, nd, st, dm);
       hipLaunchKernelGGL(k_gj_update, dim3(cdiv(nm, GJ_T), cdiv(nm, GJ_T), nd), dim3(256), 0, s, step, kb, nd, st, dm);
     }
   }
   const int ngm = std::max(1, G.ngmax);
+  nm = std::max(1, G.nmax);
   hipLaunchKernelGGL(k_gj_final_pick, dim3(cdiv(ngm, 16), cdiv(ngm, 16), nd), dim3(256), 0, s, nd, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ig);
   hipLaunchKernelGGL(k_gj_final_scatter, dim3(8, 1, nd), dim3(256), 0, s, nd, dm, P.src.p, P.dst.p, gg);
   hipLaunchKernelGGL(k_gj_final_sym, dim3(256, 1, nd), dim3(256), 0, s, nd, dm, Sd);
   if (bI && w) {
-    hipLaunchKernelGGL(k_gj_final_zg, dim3(cdiv(nm, 256), 1, nd), dim3(256), 0, s, nd, G.nsteps - 1, dm);
+    hipLaunchKernelGGL(k_gj_final_zg, dim3(cdiv(nm, 64), 1, nd), dim3(256), 0, s, nd, G.nsteps - 1, dm);
     hipLaunchKernelGGL(k_gj_final_w, dim3(cdiv(ngm, 256), 1, nd), dim3(256), 0, s, nd, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ig, w);
   }
   MI_HIP(hipGetLastError());

@@ -826,7 +826,7 @@ int mi_nn_pinv(mi_ctx_t ctx, int64_t ndom, const int64_t *n_gamma_d, const doubl
     DevBuf<double> s1, s2;
     In si(ctx, Sd, tot, s1);
     InOut po(ctx, PiSd, tot, s2, false);
-    pinv_blocks(ctx, (int)ndom, n_gamma_d, si.dev, rtol, po.dev);
+    pinv_blocks_fast(ctx, (int)ndom, n_gamma_d, si.dev, rtol, po.dev);
     po.finish();
     return MI_OK;
   });

@@ -430,6 +430,81 @@ inline void gj_run(mi_setup_s &P, const double *ii_val, const double *ig_val, co
   if (rhs) cp(w, G.out_w.p, P.n_w);
 }
 
+// ---------------------------------------------------------------- pinv of well-conditioned blocks = their inverse
+// `pinv(S_d, rtol)` keeps the singular values above rtol * σ_max. If 1 / ||S^{-1}||_inf > rtol * ||S||_inf then
+// σ_min >= 1 / ||S^{-1}||_2 >= 1 / ||S^{-1}||_inf > rtol ||S||_inf >= rtol σ_max: nothing is dropped and the pseudo-inverse IS the
+// inverse — computed by the block Gauss-Jordan kernels above in ~1 ms instead of an eigen-decomposition (~30 ms per block
+// through rocSOLVER). Blocks that fail the test (floating subdomains: S_d 1 = 0) keep the spectral route.
+__global__ __launch_bounds__(256) void k_rowsum_max(int n, const double *__restrict__ A, double *__restrict__ out) {
+  __shared__ double sm[NT / 64 + 1];
+  double m = 0.0;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+    double s2 = 0.0;
+    for (int c = 0; c < n; ++c) s2 += fabs(A[r + (size_t)c * n]);     // symmetric: column sums = row sums, coalesced this way
+    m = fmax(m, isfinite(s2) ? s2 : INFINITY);
+  }
+  // max over the workgroup through the deterministic sum helper's scratch: a max tree on wave level, then lanes 0
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+inline void pinv_blocks_fast(mi_ctx_s *c, int ndom, const int64_t *n_gamma_d, const double *Sd, double rtol, double *Pi) {
+  hipStream_t s = c->stream;
+  if (env_int("MI355_PINV_EIG", 0)) { pinv_blocks(c, ndom, n_gamma_d, Sd, rtol, Pi); return; }
+  // one-step batch of the inversion kernels: T = copy of S_d, result in Z[nb & 1]
+  std::vector<GjStep> st(ndom);
+  std::vector<GjDom> dm(ndom);
+  size_t tot = 0, nmax = 1;
+  std::vector<size_t> oT(ndom), o0(ndom), o1(ndom), oP(ndom), off(ndom);
+  size_t run = 0;
+  int nbmax = 0;
+  for (int d = 0; d < ndom; ++d) {
+    const size_t n = (size_t)n_gamma_d[d], nn = std::max<size_t>(1, n * n);
+    off[d] = run; run += n * n;
+    auto take = [&](size_t cnt) { const size_t o = tot; tot += (cnt + 31) / 32 * 32; return o; };
+    oT[d] = take(nn); o0[d] = take(nn); o1[d] = take(nn); oP[d] = take(GJ_B * GJ_B);
+    nmax = std::max(nmax, n);
+  }
+  DevBuf<double> pool(tot + 32), norms((size_t)2 * ndom * 8);
+  for (int d = 0; d < ndom; ++d) {
+    const int n = (int)n_gamma_d[d];
+    st[d] = GjStep{}; st[d].n0 = n; st[d].nb = (n + GJ_B - 1) / GJ_B;
+    dm[d] = GjDom{}; dm[d].T = pool.p + oT[d]; dm[d].Z[0] = pool.p + o0[d]; dm[d].Z[1] = pool.p + o1[d]; dm[d].P = pool.p + oP[d];
+    nbmax = std::max(nbmax, st[d].nb);
+    if (n) MI_HIP(hipMemcpyAsync(dm[d].T, Sd + off[d], sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
+  }
+  DevBuf<GjStep> std_; DevBuf<GjDom> dmd;
+  std_.upload(st, s); dmd.upload(dm, s);
+  auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+  for (int kb = 0; kb < nbmax; ++kb) {
+    hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, ndom), dim3(64), 0, s, 0, kb, ndom, std_.p, dmd.p);
+    hipLaunchKernelGGL(k_gj_update, dim3(cdiv((int)nmax, GJ_T), cdiv((int)nmax, GJ_T), ndom), dim3(256), 0, s, 0, kb, ndom, std_.p, dmd.p);
+  }
+  for (int d = 0; d < ndom; ++d) {
+    const int n = (int)n_gamma_d[d];
+    if (!n) continue;
+    hipLaunchKernelGGL(k_rowsum_max, dim3(8), dim3(256), 0, s, n, Sd + off[d], norms.p + (size_t)16 * d);
+    hipLaunchKernelGGL(k_rowsum_max, dim3(8), dim3(256), 0, s, n, dm[d].Z[st[d].nb & 1], norms.p + (size_t)16 * d + 8);
+  }
+  MI_HIP(hipGetLastError());
+  std::vector<double> nh((size_t)16 * ndom);
+  MI_HIP(hipMemcpyAsync(nh.data(), norms.p, sizeof(double) * nh.size(), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  std::vector<int> slow;
+  for (int d = 0; d < ndom; ++d) {
+    const int n = (int)n_gamma_d[d];
+    if (!n) continue;
+    double ns = 0.0, nz = 0.0;
+    for (int k = 0; k < 8; ++k) { ns = std::max(ns, nh[(size_t)16 * d + k]); nz = std::max(nz, nh[(size_t)16 * d + 8 + k]); }
+    const bool inv_ok = std::isfinite(ns) && std::isfinite(nz) && nz > 0.0 && 1.0 / nz > rtol * ns;
+    if (inv_ok) MI_HIP(hipMemcpyAsync(Pi + off[d], dm[d].Z[st[d].nb & 1], sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
+    else slow.push_back(d);
+  }
+  for (int d : slow) pinv_blocks(c, 1, n_gamma_d + d, Sd + off[d], rtol, Pi + off[d]);
+  MI_HIP(hipStreamSynchronize(s));   // the work buffers go out of scope
+}
+
 }  // namespace mi
 
 inline mi_setup_s::~mi_setup_s() { release_lanes(); }

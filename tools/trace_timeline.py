@@ -24,3 +24,23 @@ for r in t:
     gap = s - prev if prev is not None else 0
     print(f"{s / 1e3:9.1f} us dur {(e - s) / 1e3:7.2f} gap {gap / 1e3:7.2f}  {r['Kernel_Name'].split('(')[0].replace('void mi::', '')}")
     prev = e
+
+# one whole solve in the middle of the trace (k_solve_begin ... k_solve_end) and the host turnaround to the next one
+begins = [i for i, r in enumerate(rows) if "k_solve_begin" in r["Kernel_Name"]]
+if len(begins) > 4:
+    b = begins[len(begins) // 2]
+    nb = next((i for i in begins if i > b), len(rows))
+    print("\none solve (k_solve_begin .. next k_solve_begin):")
+    t0, prev = int(rows[b]["Start_Timestamp"]), None
+    for r in rows[b:nb + 1]:
+        s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+        gap = s - prev if prev is not None else 0
+        print(f"{s / 1e3:9.1f} us dur {(e - s) / 1e3:7.2f} gap {gap / 1e3:7.2f}  {r['Kernel_Name'].split('(')[0].replace('void mi::', '')}")
+        prev = e
+    turn = []
+    for i in begins[1:]:
+        if "k_solve_end" in rows[i - 1]["Kernel_Name"]:
+            turn.append(int(rows[i]["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"]))
+    if turn:
+        turn.sort()
+        print(f"host turnaround k_solve_end -> next k_solve_begin: median {turn[len(turn) // 2] / 1e3:.1f} us, min {turn[0] / 1e3:.1f} us over {len(turn)} solves")

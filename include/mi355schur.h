@@ -172,6 +172,15 @@ int mi_schur_global_device_create(mi_ctx_t ctx, int64_t ndom, int64_t n_gamma, c
                                   const int64_t *gg_colptr, const int64_t *gg_rowval, const double *gg_nzval,
                                   double reltol, int index_base, mi_op_t *op);
 
+/* mi_schur_interior_precond — the `precond` / `preconds` keyword of apply_local_schur / apply_global_schur (EPDD.jl:648-650,
+ * 609-619: `IterativeSolvers.cg(A_IIdd, rhs, Pl=precond, reltol=reltol)`) for an operator made by one of the two
+ * *_device_create calls above. kind 0: none (the default, plain CG); kind 1: Pl = Diagonal(A_IIdd) (Jacobi). The reference's own
+ * choice, an AMG hierarchy from Preconditioners.jl, is outside the hot path; the diagonal costs nothing per
+ * iteration (it is folded into the update kernel) and about halves the iteration counts on lognormal coefficient fields. */
+int mi_schur_interior_precond(mi_op_t op, int kind);
+/* Diagnostic: iterations the interior CG of such an operator has run so far (slowest subdomain, rounded up to replays). */
+int mi_schur_interior_iterations(mi_op_t op, int64_t *iterations);
+
 int mi_op_size(mi_op_t op, int64_t *n);
 /* y = A*x (operator) or y = M \ x (preconditioner); x and y must not alias. */
 int mi_op_apply(mi_op_t op, const double *x, double *y);

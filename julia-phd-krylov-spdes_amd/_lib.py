@@ -83,6 +83,8 @@ SIGNATURES = {
     "mi_dense_set_blocks": [vp, vp],
     "mi_schur_matfree_rhs": [vp, vp, vp, vp],
     "mi_schur_matfree_interior_solutions": [vp, vp, vp, vp],
+    "mi_schur_interior_precond": [vp, C.c_int],
+    "mi_schur_interior_iterations": [vp, i64p],
     "mi_eigcg": [vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],
     "mi_eigpcg": [vp, vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],
     "mi_eigdefcg": [vp, vp, vp, vp, i64, i64, i64, C.c_double, f64p, i64, i64p, vp],

@@ -472,6 +472,26 @@ def _interior_solutions(self, u_Γ, b_I):
 MatrixFreeLocalSchurs.interior_solutions = _interior_solutions
 
 
+def _interior_precond(self, kind) -> None:
+    """The `precond(s)` keyword of `apply_local_schur(s)` / `apply_global_schur` (EPDD.jl:648-650, 609-619) for the device
+    interior CG: None / "none": plain CG (the default); "diagonal": `Pl = Diagonal(A_IIdd)`."""
+    k = {None: 0, "none": 0, 0: 0, "diagonal": 1, "jacobi": 1, 1: 1}.get(kind)
+    if k is None:
+        raise ValueError("interior preconditioner: None or 'diagonal'")
+    check(self.ctx._L.mi_schur_interior_precond(self._h, C.c_int(k)))
+
+
+def _interior_iterations(self) -> int:
+    """Diagnostic: iterations the device interior CG has run so far (slowest subdomain, rounded up to whole replays)."""
+    out = i64(0)
+    check(self.ctx._L.mi_schur_interior_iterations(self._h, C.byref(out)))
+    return int(out.value)
+
+
+MatrixFreeLocalSchurs.interior_precond = _interior_precond
+MatrixFreeLocalSchurs.interior_iterations = _interior_iterations
+
+
 class LocalSchur(MatrixFreeLocalSchurs):
     """`xd -> apply_local_schur(A_IIdd, A_IΓdd, A_ΓΓdd, xd; precond, reltol)` (EPDD.jl:639-654): ONE subdomain, vectors in
     its own Γ_d numbering — S_d xd = A_ΓΓdd xd - A_IΓdd' A_IIdd^{-1} (A_IΓdd xd). What `assemble_local_schurs` applies to the
@@ -663,6 +683,8 @@ class GlobalSchur(Operator):
 
 GlobalSchur.interior_solutions = _interior_solutions      # `get_subdomain_solutions` (EPDD.jl:1014-1025), Γ-global columns
 GlobalSchur.schur_rhs = MatrixFreeLocalSchurs.schur_rhs   # `get_schur_rhs` (EPDD.jl:798-821)
+GlobalSchur.interior_precond = _interior_precond
+GlobalSchur.interior_iterations = _interior_iterations
 
 
 # reference-named free functions

@@ -725,6 +725,26 @@ int mi_schur_matfree_set_values(mi_op_t op, const double *ii_val, const double *
 static GlobalSchurOp *as_global(mi_op_t op) {
   return op && op->impl ? dynamic_cast<GlobalSchurOp *>(op->impl.get()) : nullptr;
 }
+int mi_schur_interior_precond(mi_op_t op, int kind) {
+  MatfreeSchurOp *m = as_matfree(op);
+  GlobalSchurOp *gl = as_global(op);
+  InteriorCg *icg = m ? m->icg.get() : gl ? gl->icg.get() : nullptr;
+  if (!icg) return fail(MI_ERR_BAD_ARG, "mi_schur_interior_precond: not a Schur operator with the interior solve on the device");
+  if (kind != 0 && kind != 1) return fail(MI_ERR_BAD_ARG, "mi_schur_interior_precond: kind must be 0 (none) or 1 (diagonal)");
+  return guarded([&]() -> int {
+    op->impl->ctx->use();
+    icg->set_jacobi(kind == 1);
+    return MI_OK;
+  });
+}
+int mi_schur_interior_iterations(mi_op_t op, int64_t *iterations) {
+  MatfreeSchurOp *m = as_matfree(op);
+  GlobalSchurOp *gl = as_global(op);
+  InteriorCg *icg = m ? m->icg.get() : gl ? gl->icg.get() : nullptr;
+  if (!icg || !iterations) return fail(MI_ERR_BAD_ARG, "mi_schur_interior_iterations: not a Schur operator with the interior solve on the device");
+  *iterations = icg->total_iterations;
+  return MI_OK;
+}
 int mi_schur_matfree_rhs(mi_op_t op, const double *b_I, const double *b_gamma, double *b_schur) {
   MatfreeSchurOp *m = as_matfree(op);
   GlobalSchurOp *gl = as_global(op);

@@ -565,6 +565,17 @@ struct InteriorCg {
   double *graph_x = nullptr;
   IcgMeta meta{};
   long long total_iterations = 0;  // statistics: iterations of the slowest subdomain, summed over solves
+  // 2-launch form (k_icg_spmv / k_icg_update_blk): default; MI355_ICG_UNFUSED=1 keeps the 3-launch loop
+  bool folded = true;
+  IcgFold fm{};
+  DevBuf<IcgPiece> pieces;
+  DevBuf<IcgDomState> dst;   // cur[ndl], nxt[ndl]
+  DevBuf<double> ur, part_rz, dinv;
+  DevBuf<int> dom_p0, dom_p1;
+  IcgDomState *dst_host = nullptr;
+  std::vector<int> ioff_h;
+  int npieces_grid = 0;
+  bool jacobi = false;       // `Pl` = Diagonal(A_II) (mi_schur_matfree_interior_precond)
 
   void build(mi_ctx_s *c_, const HostCsr &a, const std::vector<int> &ioff, const std::vector<int> &ni, double reltol_) {
     ctx = c_; reltol = reltol_; ndl = (int)ni.size(); n = a.n_rows;
@@ -588,13 +599,88 @@ struct InteriorCg {
     MI_HIP(hipHostMalloc((void **)&done_host, sizeof(int) * (ndl + 1)));
     chunk = std::max(1, env_int("MI355_ICG_CHUNK", 64));
     meta = IcgMeta{A.blk.p, blk_dom.p, dom_b0.p, dom_b1.p, res_cur.p, res_nxt.p, tol.p, done_cur.p, done_nxt.p, iters.p, 0};
+    folded = !env_int("MI355_ICG_UNFUSED", 0);
+    ioff_h = ioff;
+    if (folded) build_fold(a, b0, b1);
+  }
+  // Pieces of the vector kernel: rows cut at subdomain boundaries and at the XCD boundaries of the SpMV's block dealing,
+  // then into runs of <= `rows_per` rows; workgroup k works on XCD k & 7, so the pieces are interleaved per XCD.
+  void build_fold(const HostCsr &a, const std::vector<int> &b0, const std::vector<int> &b1) {
+    hipStream_t s = ctx->stream;
+    const int per = (A.nblocks + 7) >> 3;
+    std::vector<int> xr(9, n);
+    for (int x = 0; x < 8; ++x) xr[x] = x * per < A.nblocks ? A.blocks_h[(size_t)x * per].r0 : n;
+    const int target = std::max(256, env_int("MI355_ICG_PIECES", 512));   // about this many pieces in all
+    const int rows_per = std::max(NT, (n + target - 1) / target);
+    std::vector<std::vector<IcgPiece>> per_xcd(8);
+    std::vector<int> p0(ndl, 0), p1(ndl, 0);
+    int slot = 0;
+    bool ok = true;
+    for (int d = 0; d < ndl; ++d) {
+      p0[d] = slot;
+      const int lo_d = ioff_h[d], hi_d = d + 1 < (int)ioff_h.size() ? ioff_h[d + 1] : n;
+      for (int x = 0; x < 8; ++x) {
+        const int lo = std::max(lo_d, xr[x]), hi = std::min(hi_d, xr[x + 1]);
+        if (hi <= lo) continue;
+        const int cnt = (hi - lo + rows_per - 1) / rows_per;
+        for (int k = 0; k < cnt; ++k) {
+          const int a0 = lo + (int)((long long)(hi - lo) * k / cnt), a1 = lo + (int)((long long)(hi - lo) * (k + 1) / cnt);
+          per_xcd[x].push_back(IcgPiece{a0, a1, d, slot++});
+        }
+      }
+      p1[d] = slot;
+      if (p1[d] - p0[d] > NT) ok = false;   // k_icg_spmv sums a subdomain's partials with one load per thread
+    }
+    if (!ok) { folded = false; return; }
+    size_t mx = 0;
+    for (auto &v : per_xcd) mx = std::max(mx, v.size());
+    std::vector<IcgPiece> tab(8 * std::max<size_t>(1, mx), IcgPiece{0, 0, 0, 0});
+    for (int x = 0; x < 8; ++x)
+      for (size_t j = 0; j < per_xcd[x].size(); ++j) tab[j * 8 + x] = per_xcd[x][j];
+    npieces_grid = (int)tab.size();
+    pieces.upload(tab, s);
+    dom_p0.upload(p0, s); dom_p1.upload(p1, s);
+    std::vector<IcgDomState> st0(2 * (size_t)ndl);
+    for (auto &q : st0) { q.rho_prev = 1.0; q.tol = 0.0; q.res = 0.0; q.it = 0; q.done = 1; }   // an empty interior stays "done"
+    dst.upload(st0, s);
+    ur.alloc(4 * (size_t)n + 4); part_rz.alloc((size_t)slot + 1);
+    if (p_rr.n < (size_t)slot + 1) p_rr.alloc((size_t)slot + 1);
+    MI_HIP(hipHostMalloc((void **)&dst_host, sizeof(IcgDomState) * (ndl + 1)));
+    // diagonal of A_II (for the optional Jacobi `Pl`)
+    std::vector<double> dg((size_t)n + 1, 1.0);
+    for (int r = 0; r < a.n_rows; ++r)
+      for (int k = a.rowptr[r]; k < a.rowptr[r + 1]; ++k)
+        if (a.col[k] == r) dg[r] = 1.0 / a.val[k];
+    dinv.upload(dg, s);
+    fm = IcgFold{A.blk.p, blk_dom.p, dom_b0.p, dom_b1.p, dom_p0.p, dom_p1.p, n_i.p, dst.p, dst.p + ndl, ur.p, ur.p + 2 * (size_t)n,
+                 c.p, r.p, p_uc.p, p_rr.p, part_rz.p, nullptr, reltol};
   }
   ~InteriorCg() {
     if (graph) (void)hipGraphExecDestroy(graph);
     if (done_host) (void)hipHostFree(done_host);
+    if (dst_host) (void)hipHostFree(dst_host);
+  }
+  void set_jacobi(bool on) {
+    if (on && !folded) raise(MI_ERR_BAD_ARG, "the diagonal interior preconditioner needs the 2-launch interior CG");
+    if (on != jacobi && graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
+    jacobi = on;
+    fm.dinv = on ? dinv.p : nullptr;
+  }
+  // after new values of A_II: 1 / diagonal again (device side)
+  void refresh_diagonal() {
+    if (!folded || n == 0) return;
+    hipLaunchKernelGGL(k_csr_inv_diag, dim3((n + NT - 1) / NT), dim3(NT), 0, ctx->stream, n, A.rowptr.p, A.col.p, A.val.p, dinv.p);
+    MI_HIP(hipGetLastError());
   }
   void iteration(double *x) {
     hipStream_t s = ctx->stream;
+    if (folded) {
+      const int grid = ((A.nblocks + 7) / 8) * 8;
+      hipLaunchKernelGGL(k_icg_spmv, dim3(grid), dim3(NT), 0, s, A.nblocks, fm, A.rowptr.p, A.col.p, A.val.p);
+      hipLaunchKernelGGL(k_icg_update_blk, dim3(npieces_grid), dim3(NT), 0, s, fm, pieces.p, x);
+      MI_HIP(hipGetLastError());
+      return;
+    }
     A.launch(0, u.p, nullptr, c.p, nullptr, s, u.p, p_uc.p);  // c = A u, partial u'c
     hipLaunchKernelGGL(k_icg_update, dim3(A.nblocks), dim3(NT), 0, s, meta, p_uc.p, u.p, c.p, x, r.p, p_rr.p);
     hipLaunchKernelGGL(k_icg_direction, dim3(A.nblocks), dim3(NT), 0, s, meta, p_rr.p, r.p, u.p, n_i.p);
@@ -604,8 +690,12 @@ struct InteriorCg {
   void solve(const double *rhs, double *x) {
     if (A.nblocks == 0) return;
     hipStream_t s = ctx->stream;
-    hipLaunchKernelGGL(k_icg_init, dim3(A.nblocks), dim3(NT), 0, s, meta, rhs, x, r.p, u.p, p_rr.p);
-    hipLaunchKernelGGL(k_icg_start, dim3(ndl), dim3(NT), 0, s, meta, p_rr.p, reltol);
+    if (folded) {
+      hipLaunchKernelGGL(k_icg_fold_init, dim3(npieces_grid), dim3(NT), 0, s, fm, pieces.p, rhs, x);
+    } else {
+      hipLaunchKernelGGL(k_icg_init, dim3(A.nblocks), dim3(NT), 0, s, meta, rhs, x, r.p, u.p, p_rr.p);
+      hipLaunchKernelGGL(k_icg_start, dim3(ndl), dim3(NT), 0, s, meta, p_rr.p, reltol);
+    }
     MI_HIP(hipGetLastError());
     if (!graph || graph_x != x) {  // `chunk` iterations per replay
       if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
@@ -626,10 +716,16 @@ struct InteriorCg {
     }
     const long long max_replays = (long long)n / chunk + 2;  // maxiter = size(A, 2)
     for (long long l = 0; l <= max_replays; ++l) {
-      MI_HIP(hipMemcpyAsync(done_host, done_nxt.p, sizeof(int) * ndl, hipMemcpyDeviceToHost, s));
-      MI_HIP(hipStreamSynchronize(s));
       bool all = true;
-      for (int d = 0; d < ndl; ++d) all = all && done_host[d];
+      if (folded) {
+        MI_HIP(hipMemcpyAsync(dst_host, dst.p, sizeof(IcgDomState) * ndl, hipMemcpyDeviceToHost, s));   // cur[]
+        MI_HIP(hipStreamSynchronize(s));
+        for (int d = 0; d < ndl; ++d) all = all && dst_host[d].done;
+      } else {
+        MI_HIP(hipMemcpyAsync(done_host, done_nxt.p, sizeof(int) * ndl, hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+        for (int d = 0; d < ndl; ++d) all = all && done_host[d];
+      }
       if (all) break;
       MI_HIP(hipGraphLaunch(graph, s));
       total_iterations += chunk;
@@ -729,6 +825,7 @@ struct MatfreeSchurOp : Operator {
     if (ii_val) {
       if (!icg) raise(MI_ERR_BAD_ARG, "set_values: A_II lives in the interior-solve callback of this operator");
       if (icg->A.nnz) MI_HIP(hipMemcpyAsync(icg->A.val.p, ii_val, sizeof(double) * icg->A.nnz, hipMemcpyDeviceToDevice, s));
+      icg->refresh_diagonal();
     }
     if (ig_val && A_GI.nnz) {
       MI_HIP(hipMemcpyAsync(A_GI.val.p, ig_val, sizeof(double) * A_GI.nnz, hipMemcpyDeviceToDevice, s));

@@ -12,6 +12,8 @@
 // speculatively behind it. If the stop flag is not up, `chunk`-sized replays follow, the host
 // looking at the flag of the PREVIOUS replay (one replay of run-ahead).
 #pragma once
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <tuple>
@@ -141,10 +143,15 @@ struct SolverWorkspace {
   int e_spdim = 0, e_nvec = 0;
   bool e_av = false;
   PinnedFlags *flags = nullptr;    // 2 slots, pinned
+  SolveArgs *args = nullptr;       // pinned: per-call arguments of a whole-solve graph (k_solve_begin_g)
+  DevBuf<SolveArgs> args_dev;      // its device copy for k_solve_end_g, + the exit kernel's workgroup counter
+  DevBuf<unsigned> end_count;
+  unsigned long long seq = 0;
   double *res_stage = nullptr;     // pinned landing zone for short residual histories
   hipEvent_t ev[2] = {nullptr, nullptr};
   std::map<GraphKey, hipGraphExec_t> graphs;
   std::map<GraphKey, int> predicted;  // loop iterations the last solve with this (A, M, nvec) took
+  std::map<GraphKey, bool> zero_x0;   // ... and whether its initial guess was identically zero (whole-solve graphs)
   std::map<std::pair<const Operator *, const Operator *>, std::unique_ptr<ResidentPlan>> resident;  // per (S, ΠS) pair
 
   explicit SolverWorkspace(int64_t n_) : n(n_), g(vec_grid(n_)) {
@@ -160,12 +167,17 @@ struct SolverWorkspace {
     r = (double *)q; q += vec; z = (double *)q; q += vec; p = (double *)q; q += vec;
     Ap = (double *)q; q += vec; x = (double *)q; q += vec; b = (double *)q; q += vec;
     MI_HIP(hipHostMalloc((void **)&flags, 2 * sizeof(PinnedFlags)));
+    std::memset(flags, 0, 2 * sizeof(PinnedFlags));
+    MI_HIP(hipHostMalloc((void **)&args, sizeof(SolveArgs)));
+    args_dev.alloc(1); end_count.alloc(1);
+    MI_HIP(hipMemset(end_count.p, 0, sizeof(unsigned)));
     MI_HIP(hipHostMalloc((void **)&res_stage, RES_STAGE * sizeof(double)));
     for (auto &e : ev) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   ~SolverWorkspace() {
     drop_graphs();
     if (flags) (void)hipHostFree(flags);
+    if (args) (void)hipHostFree(args);
     if (res_stage) (void)hipHostFree(res_stage);
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
   }
@@ -179,6 +191,9 @@ struct SolverWorkspace {
       else ++it;
     for (auto it = predicted.begin(); it != predicted.end();)
       if (it->first.A == op || it->first.M == op) it = predicted.erase(it);
+      else ++it;
+    for (auto it = zero_x0.begin(); it != zero_x0.end();)
+      if (it->first.A == op || it->first.M == op) it = zero_x0.erase(it);
       else ++it;
     for (auto it = resident.begin(); it != resident.end();)
       if (it->first.first == op || it->first.second == op) it = resident.erase(it);
@@ -246,6 +261,7 @@ struct Krylov {
   CsrDev *Ac = nullptr;  // cg / pcg with a diagonal M on a plain sparse matrix: the 2-launch loop (k_spmv_pcg, k_update_xr_blk)
   bool csrfold() const { return Ac != nullptr && !eig.tag; }
   DenseBlockOp *Ad = nullptr, *Md = nullptr;
+  int capture_whole = 0;  // while a whole-solve graph is being captured: 1 general entry, 2 entry for x0 == 0 (folded loop)
   // eigCG family: recording kernels after every iteration (eig_solvers.hpp fills this in)
   struct EigHook {
     int tag = 0, spdim = 0;
@@ -287,6 +303,7 @@ struct Krylov {
     f.part_rows = Ad->reduce_over_ranks ? 1 : 0;
     f.nvec = nvec; f.n_gamma = n;
     if (nvec > 0) { f.AW = ws.AW.p; f.part_mu = ws.fold_mu.p; f.wm_loc = ws.fold_wm.p; }
+    if (capture_whole && phase == 0) { f.exit_args = ws.args_dev.p; f.exit_flags = &ws.flags[0]; }
     f.n_in = phase ? (f.part_rows ? Ad->maps.nloc : Ad->ntiles) : Md->ntiles;
     const bool red = Ad->reduce_over_ranks;  // the S launch's outputs are summed over the ranks before the ΠS launch reads them
     if (phase) {  // ΠS launch: reads S contributions + partial p'Ap, writes ΠS contributions + partial r'r, r'z
@@ -502,17 +519,37 @@ struct Krylov {
     MI_HIP(hipGetLastError());
   }
 
-  // chunk > 0: `chunk` iterations; chunk < 0: set-up tail + (-chunk) iterations.
-  hipGraphExec_t graph(int chunk) {
-    GraphKey key{A, M, nvec, chunk, eig.tag * 8 + (fused ? 1 : 0) + (fold ? 2 : 0) + (csrfold() ? 4 : 0)};  // the loop form is part of the graph
+  // chunk > 0: `chunk` iterations; chunk < 0: set-up tail + (-chunk) iterations; whole: the entry kernel in front of
+  // and the exit kernel behind them (arguments through ws.args), so that a solve is ONE replay.
+  hipGraphExec_t graph(int chunk, int whole = 0) {
+    GraphKey key{A, M, nvec, chunk, eig.tag * 8 + (fused ? 1 : 0) + (fold ? 2 : 0) + (csrfold() ? 4 : 0) + 1024 * whole};  // the loop form is part of the graph
     auto it = ws.graphs.find(key);
     if (it != ws.graphs.end()) return it->second;
     hipGraph_t gr = nullptr;
     MI_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     try {
-      if (chunk < 0) setup_tail();
+      capture_whole = whole;
+      if (whole == 2) {   // folded loop, x0 == 0: one entry launch
+#define MI_CALL(E) hipLaunchKernelGGL((k_entry_zero<E>), dim3(1), dim3(NTF), 0, s, n, ws.args, ws.b, ws.x, ws.r, ws.st, ws.args_dev.p, &ws.flags[0])
+        MI_EPT_DISPATCH(MI_CALL);
+#undef MI_CALL
+        MI_HIP(hipGetLastError());
+      } else {
+        if (whole) {
+          hipLaunchKernelGGL(k_solve_begin_g, dim3(g), dim3(NT), 0, s, n, ws.args, ws.b, ws.x, ws.st, ws.args_dev.p);
+          MI_HIP(hipGetLastError());
+        }
+        if (chunk < 0) setup_tail();
+      }
       for (int k = 0; k < std::abs(chunk); ++k) iteration();
+      capture_whole = 0;
+      if (whole) {
+        hipLaunchKernelGGL(k_solve_end_g, dim3(g), dim3(NT), 0, s, n, ws.st, ws.args_dev.p, (int)(fold || csrfold()), ws.x, ws.res_norm.p,
+                           &ws.flags[0], &ws.st->x0_zero, ws.end_count.p);
+        MI_HIP(hipGetLastError());
+      }
     } catch (...) {
+      capture_whole = 0;
       (void)hipStreamEndCapture(s, &gr);
       if (gr) (void)hipGraphDestroy(gr);
       throw;
@@ -526,6 +563,21 @@ struct Krylov {
     return ex;
   }
 
+  // Wait for the exit kernel of a whole-solve graph: it stores the solve number after everything else it wrote has been
+  // released to system scope. A bounded spin (a replay that takes longer, or a fault, ends in a stream synchronisation).
+  void wait_seq(unsigned long long seq) {
+    volatile unsigned long long *f = &ws.flags[0].seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned k = 1;; ++k) {
+      if (*f == seq) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+      if ((k & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+      __builtin_ia32_pause();
+    }
+    MI_HIP(hipStreamSynchronize(s));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (*f != seq) raise(MI_ERR_HIP, "internal: the solve's exit kernel did not report (seq %llu, expected %llu)", (unsigned long long)*f, seq);
+  }
+
   void fetch_flags(int slot) {
     MI_HIP(hipMemcpyAsync(&ws.flags[slot].it, (fold || csrfold()) ? &ws.st->it_nxt : &ws.st->it, sizeof(long long),
                           hipMemcpyDeviceToHost, s));
@@ -536,6 +588,26 @@ struct Krylov {
   // Common entry of every solver: b, x to the workspace; eps / maxit / res_cap to the state block; deflated
   // solvers: W, WtA, WtAW (LU on the host) and the deflated initial guess (defcg.jl:40-54 / 260-275).
   void begin(const double *b_in, const double *x_in, const double *W_in, int64_t &maxit, double &eps, int64_t &cap_dev) {
+    prepare(maxit, eps, cap_dev);
+    const size_t vb = sizeof(double) * (size_t)n;
+    hipLaunchKernelGGL(k_solve_begin, dim3(g), dim3(NT), 0, s, n, b_in, x_in, ws.b, ws.x, ws.st, eps, (long long)maxit,
+                       (long long)cap_dev);
+    MI_HIP(hipGetLastError());
+    if (nvec > 0) {
+      MI_HIP(hipMemcpyAsync(ws.W.p, W_in, vb * nvec, hipMemcpyDeviceToDevice, s));
+      A->apply_multi(ws.W.p, n, nvec, ws.AW.p, n);                           // WtA[v,:] = A*W[:,v]
+      hipLaunchKernelGGL(k_small_gram, dim3(nvec, nvec), dim3(NT), 0, s, n, ws.AW.p, ws.W.p, ws.gram.p, nvec);  // WtAW
+      MI_HIP(hipGetLastError());
+      factor(ws.gram.p, ws.LU, ws.piv, &gram_host, "WtAW");
+      A->apply(ws.x, ws.Ap, nullptr);                                        // r .= b .- A*x
+      hipLaunchKernelGGL(k_residual, dim3(g), dim3(NT), 0, s, n, ws.b, ws.Ap, ws.r, ws.part_rr, ws.part_bb);
+      project(ws.W.p, ws.r, nullptr);                                        // mu = WtAW \ (W'r)
+      hipLaunchKernelGGL(k_add_Wmu, dim3(g), dim3(NT), 0, s, n, ws.x, ws.W.p, ws.mu.p, nvec);  // x .+= W*mu
+      MI_HIP(hipGetLastError());
+    }
+  }
+  // host half of the entry: defaults, capacities, buffers
+  void prepare(int64_t &maxit, double &eps, int64_t &cap_dev) {
     if (eps <= 0.0) eps = 1e-7;           // RecyclingKrylovSolvers.jl:21
     if (maxit == 0) maxit = n;            // cg.jl:25
     // reference: res_norm has n entries and `res_norm[it] = ...` throws BoundsError at it = n + 1 (cg.jl:23,47), which
@@ -558,22 +630,6 @@ struct Krylov {
         ws.cf_pz.alloc(need_pz); ws.cf_rr.alloc(need_p); ws.cf_rz.alloc(need_p);
       }
     }
-    const size_t vb = sizeof(double) * (size_t)n;
-    hipLaunchKernelGGL(k_solve_begin, dim3(g), dim3(NT), 0, s, n, b_in, x_in, ws.b, ws.x, ws.st, eps, (long long)maxit,
-                       (long long)cap_dev);
-    MI_HIP(hipGetLastError());
-    if (nvec > 0) {
-      MI_HIP(hipMemcpyAsync(ws.W.p, W_in, vb * nvec, hipMemcpyDeviceToDevice, s));
-      A->apply_multi(ws.W.p, n, nvec, ws.AW.p, n);                           // WtA[v,:] = A*W[:,v]
-      hipLaunchKernelGGL(k_small_gram, dim3(nvec, nvec), dim3(NT), 0, s, n, ws.AW.p, ws.W.p, ws.gram.p, nvec);  // WtAW
-      MI_HIP(hipGetLastError());
-      factor(ws.gram.p, ws.LU, ws.piv, &gram_host, "WtAW");
-      A->apply(ws.x, ws.Ap, nullptr);                                        // r .= b .- A*x
-      hipLaunchKernelGGL(k_residual, dim3(g), dim3(NT), 0, s, n, ws.b, ws.Ap, ws.r, ws.part_rr, ws.part_bb);
-      project(ws.W.p, ws.r, nullptr);                                        // mu = WtAW \ (W'r)
-      hipLaunchKernelGGL(k_add_Wmu, dim3(g), dim3(NT), 0, s, n, ws.x, ws.W.p, ws.mu.p, nvec);  // x .+= W*mu
-      MI_HIP(hipGetLastError());
-    }
   }
   // LU (host, LAPACK getrf order) of the nvec x nvec device matrix `gram`; factors and pivots back to the device.
   void factor(const double *gram, DevBuf<double> &LU, DevBuf<int> &piv, std::vector<double> *keep, const char *name) {
@@ -593,10 +649,15 @@ struct Krylov {
   int solve(const double *b_in, double *x_io, const double *W_in, int64_t maxit, double eps, double *res_host,
             int64_t res_cap, int64_t *it_out) {
     int64_t cap_dev = 0;
-    begin(b_in, x_io, W_in, maxit, eps, cap_dev);
+    bool use_graph = ctx->chunk > 0 && A->graph_safe() && (!M || M->graph_safe()) && !ctx->no_graph;
+    // Undeflated solves on one GPU: entry kernel, set-up, iterations and exit kernel are ONE graph replay whose per-call
+    // arguments travel through a pinned block, and the host waits for the exit kernel's last store instead of the stream.
+    const bool whole_on = !env_int("MI355_NO_WHOLE_GRAPH", 0);
+    const bool whole = whole_on && use_graph && nvec == 0 && !eig.tag && !ctx->has_comm() && !resident_plan();
+    if (whole) prepare(maxit, eps, cap_dev);
+    else begin(b_in, x_io, W_in, maxit, eps, cap_dev);
 
     // ---- set-up tail + loop
-    bool use_graph = ctx->chunk > 0 && A->graph_safe() && (!M || M->graph_safe()) && !ctx->no_graph;
     const int64_t ncap = std::min<int64_t>(res_cap, cap_dev);
     const bool spec_res = res_host && ncap > 0 && ncap <= RES_STAGE;
     auto enqueue_results = [&](int slot) {
@@ -650,9 +711,11 @@ struct Krylov {
       if (first > 64) first -= first % 32;
       first = std::max<int64_t>(1, std::min<int64_t>(first, std::min<int64_t>(maxit, 1024)));
       if (ws.graphs.size() > 48) ws.drop_graphs();
+      // folded loop: the entry for x0 == 0 when the previous solve with these operators had one (checked on the device)
+      bool zero_variant = whole && fold && ws.zero_x0[pk] && !env_int("MI355_NO_ZERO_ENTRY", 0);
       hipGraphExec_t g0 = nullptr;
       try {
-        g0 = graph(-(int)first);
+        g0 = graph(-(int)first, whole ? (zero_variant ? 2 : 1) : 0);
       } catch (const Error &) {
         // A collective that cannot be captured (communicator attached): run this context eagerly from now on.
         // Every rank takes the same path because capture fails or succeeds identically on all of them.
@@ -661,9 +724,27 @@ struct Krylov {
         use_graph = false;
       }
       if (use_graph) {
-      MI_HIP(hipGraphLaunch(g0, s));
-      enqueue_results(0);
-      MI_HIP(hipStreamSynchronize(s));
+      if (whole) {
+        const unsigned long long seq = ++ws.seq;
+        *ws.args = SolveArgs{b_in, x_io, x_io, spec_res ? ws.res_stage : (double *)nullptr, eps, (long long)maxit, (long long)cap_dev,
+                             (long long)ncap, seq};
+        MI_HIP(hipGraphLaunch(g0, s));
+        wait_seq(seq);
+        if (ws.flags[0].respec) {   // x0 was not zero after all: the general form, and no such guess next time
+          zero_variant = false;
+          ws.zero_x0[pk] = false;
+          g0 = graph(-(int)first, 1);
+          const unsigned long long seq2 = ++ws.seq;
+          ws.args->seq = seq2;
+          MI_HIP(hipGraphLaunch(g0, s));
+          wait_seq(seq2);
+        }
+        if (fold) ws.zero_x0[pk] = ws.flags[0].x0z != 0;
+      } else {
+        MI_HIP(hipGraphLaunch(g0, s));
+        enqueue_results(0);
+        MI_HIP(hipStreamSynchronize(s));
+      }
       if (!ws.flags[0].done) {
         hipGraphExec_t ex = graph(ctx->chunk);
         const int64_t max_launch = (maxit + ctx->chunk - 1) / ctx->chunk + 2;

@@ -31,7 +31,7 @@ import Fem: apply_local_schur, apply_local_schurs, apply_global_schur, apply_neu
 # new names only (none of them is exported by Fem or RecyclingKrylovSolvers)
 export MiContext, MiOperator, MiPrecond,
        LocalSchurs, LocalSchur, MatrixFreeLocalSchurs, GlobalSchur,
-       AssemblyPlan, assemble!, set_values!, SchurSetup, set_blocks!
+       AssemblyPlan, assemble!, set_values!, SchurSetup, set_blocks!, interior_precond!, interior_iterations
 
 const lib = get(ENV, "MI355SCHUR_LIB", "libmi355schur")
 const MI_ERR_SINGULAR = Cint(-3)
@@ -358,6 +358,14 @@ end
 set_values!(S::MiOperator, ii, ig, gg) =
   check(ccall((:mi_schur_matfree_set_values, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
               S.h, ii === nothing ? C_NULL : ii, ig === nothing ? C_NULL : ig, gg === nothing ? C_NULL : gg))
+"""`interior_precond!(S, :diagonal)`: the `precond(s)` keyword of apply_local_schur(s) / apply_global_schur (EPDD.jl:648-650)
+for the device interior CG — `:none` (default, plain CG) or `:diagonal` (`Pl = Diagonal(A_IIdd)`)."""
+interior_precond!(S::MiOperator, kind::Symbol) =
+  check(ccall((:mi_schur_interior_precond, lib), Cint, (Ptr{Cvoid}, Cint), S.h, kind === :diagonal ? 1 : 0))
+function interior_iterations(S::MiOperator)
+  it = Ref{Int64}(0)
+  check(ccall((:mi_schur_interior_iterations, lib), Cint, (Ptr{Cvoid}, Ref{Int64}), S.h, it)); it[]
+end
 function get_schur_rhs(S::MiOperator, b_I::Vector{Float64}, b_Γ::Vector{Float64})      # EPDD.jl:835-864
   out = similar(b_Γ)
   check(ccall((:mi_schur_matfree_rhs, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), S.h, b_I, b_Γ, out)); out

@@ -452,6 +452,89 @@ def test_matrix_free_device_interior_cg(pkg, ctx, orc, ragged):
     assert abs(it - ite) <= 1 and np.linalg.norm(x - xe) <= 1e-5 * np.linalg.norm(xe)
 
 
+def test_whole_solve_graph_entry_exit_and_speculation(pkg, ctx, orc, toy, monkeypatch):
+    """Undeflated solves replay ONE graph (entry kernel .. exit kernel, arguments through a pinned block) and the host waits
+    for the exit's last store. The folded loop adds an entry built for x0 == 0 (chosen when the previous solve with the
+    same operators had a zero guess, verified on the device, replayed in the general form otherwise) and hands the results
+    over from the launch that meets the stop rule. All of it must be invisible: same x, it, history as the step-by-step
+    path (MI355_NO_WHOLE_GRAPH=1), bit for bit, through every transition — zero guess, non-zero guess (mis-speculation),
+    zero again, -0.0, a solve that needs more iterations than the replay holds, maxit hit, torch device vectors."""
+    import torch
+    api = pkg.api
+    P = toy
+    S, M = gpu_ops(pkg, ctx, P)
+    n, b = P.sub.n_Γ, P.b_schur
+    rng = np.random.default_rng(5)
+    x1 = rng.standard_normal(n)
+    negz = np.zeros(n); negz[::3] = -0.0
+    cases = [dict(x=np.zeros(n)), dict(x=np.zeros(n)), dict(x=x1), dict(x=x1), dict(x=np.zeros(n)), dict(x=negz), dict(x=np.zeros(n), eps=1e-3),
+             dict(x=np.zeros(n), eps=1e-12), dict(x=np.zeros(n), maxit=3), dict(x=x1, maxit=2), dict(x=np.zeros(n))]
+    def run():
+        out = []
+        for c in cases:
+            x, it, res = api.pcg(S, b, c["x"].copy(), M, maxit=c.get("maxit", 0), eps=c.get("eps", 1e-7))
+            out.append((x.copy(), it, res.copy()))
+        xt = torch.zeros(n, dtype=torch.float64, device="cuda")
+        x, it, res = api.pcg(S, torch.from_numpy(b).cuda(), xt, M)
+        out.append((x.cpu().numpy(), it, np.asarray(res).copy()))
+        x, it, res = api.cg(S, b, np.zeros(n))                       # fused 4-launch loop: general entry, exit kernel in the graph
+        out.append((x.copy(), it, res.copy()))
+        return out
+    got = run()
+    monkeypatch.setenv("MI355_NO_WHOLE_GRAPH", "1")
+    ref = run()
+    monkeypatch.delenv("MI355_NO_WHOLE_GRAPH")
+    for (x, it, res), (xr, itr, resr) in zip(got, ref):
+        assert it == itr and np.array_equal(x, xr) and np.array_equal(res, resr)
+    So, Mo = orc_ops(orc, P)
+    assert_history(got[0], orc.pcg(So, b, np.zeros(n), Mo))
+    assert_history(got[2], orc.pcg(So, b, x1.copy(), Mo))
+
+
+def test_interior_cg_two_launch_form_and_diagonal_precond(pkg, ctx, orc, fem, ragged, monkeypatch):
+    """The interior CG runs 2 launches per iteration (k_icg_spmv / k_icg_update_blk: the direction is formed on the fly from
+    gathered (u, z) pairs); MI355_ICG_UNFUSED=1 keeps round 1's 3-launch loop. Both restate the same iteration
+    (IterativeSolvers.cg, EPDD.jl:648-650), so they agree to the order of the interior tolerance, with the same bar as
+    against the oracle. `interior_precond("diagonal")` is the `precond` keyword with Pl = Diagonal(A_IIdd): same answer
+    to the interior tolerance, fewer iterations; new block values refresh the diagonal."""
+    api = pkg.api
+    P = ragged
+    n = P.sub.n_Γ
+    v = np.random.default_rng(22).standard_normal(n)
+    args = (ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, P.sub.node_Γ_cnt, None)
+    for reltol in (1e-9, 1e-5):
+        S2 = api.MatrixFreeLocalSchurs(*args, reltol=reltol)
+        monkeypatch.setenv("MI355_ICG_UNFUSED", "1")
+        S3 = api.MatrixFreeLocalSchurs(*args, reltol=reltol)
+        monkeypatch.delenv("MI355_ICG_UNFUSED")
+        So = orc.apply_local_schurs_matfree_operator(P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, n,
+                                                     orc.interior_cg_solvers(P.A_IIdd, reltol))
+        want = So * v
+        bar = 0.5 * reltol * np.abs(want).max()
+        y2, y3 = S2 * v, S3 * v
+        assert np.allclose(y2, want, rtol=0, atol=bar) and np.allclose(y3, want, rtol=0, atol=bar)
+        assert np.array_equal(S2 * v, y2)                                  # replays are deterministic
+    exact = api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt) * v
+    Sp, Sj = api.MatrixFreeLocalSchurs(*args), api.MatrixFreeLocalSchurs(*args)
+    Sj.interior_precond("diagonal")
+    yp, yj = Sp * v, Sj * v
+    assert np.allclose(yp, exact, rtol=0, atol=1e-7 * np.abs(exact).max())
+    assert np.allclose(yj, exact, rtol=0, atol=1e-7 * np.abs(exact).max())
+    assert 0 < Sj.interior_iterations() <= Sp.interior_iterations()
+    assert not np.any(Sj * np.zeros(n))
+    Sj.interior_precond(None)
+    assert np.array_equal(Sj * v, yp)                                      # back to the plain iteration, bit for bit
+    with pytest.raises(pkg.api.MiError):
+        api.MatrixFreeLocalSchurs(*args[:-1], P.solvers).interior_precond("diagonal")   # host-callback interior solve: nothing to precondition
+    # global-Schur form of the same solve (EPDD.jl:596-625)
+    coeff = lognormal_coeff(fem, P.mesh.points, 7)
+    A_IIg, A_IΓg, A_ΓΓ, _, _ = fem.prepare_global_schur(P.mesh.cells, P.mesh.points, P.epart, P.sub, coeff, f_m1, u0734)
+    G = api.GlobalSchur(ctx, A_IIg, A_IΓg, A_ΓΓ, None)
+    yg = G * v
+    G.interior_precond("diagonal")
+    assert np.allclose(G * v, yg, rtol=0, atol=1e-6 * np.abs(yg).max())
+
+
 def test_deflation_with_many_vectors(pkg, ctx, orc, toy):
     """nvec > 64 takes the generic projection kernels (k_multi_dot_partial + k_lu_solve) instead of the one-wave
     solve inside the fused p-update; nvec = 1 and nvec = 64 sit on the edges of the in-kernel path."""

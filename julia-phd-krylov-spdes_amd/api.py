@@ -31,7 +31,8 @@ EPS = 1e-7  # RecyclingKrylovSolvers.jl:21 `const eps = 1e-7`
 
 
 def _is_torch(x) -> bool:
-    return type(x).__module__.split(".")[0] == "torch"
+    t = type(x)
+    return t is not np.ndarray and t.__module__.startswith("torch")
 
 
 def _f64(a):
@@ -68,6 +69,15 @@ class Context:
         mode = _lib.MI_PTR_DEVICE if dev else _lib.MI_PTR_HOST
         check(self._L.mi_ctx_set_pointer_mode(self._h, mode))
         return mode
+
+    def _res_buffer(self, cap: int):
+        """Landing zone of a solve's residual history, kept per context (one allocation and one address lookup instead of
+        one per solve: `ndarray.ctypes` alone costs several microseconds, a fifth of what a 15-iteration solve's launch does)."""
+        buf = getattr(self, "_res", None)
+        if buf is None or buf[0].size < cap:
+            a = np.empty(max(cap, 64))
+            buf = self._res = (a, C.cast(a.ctypes.data, f64p))
+        return buf
 
     @staticmethod
     def _ptr(v, n: Optional[int] = None, writable: bool = False):
@@ -719,10 +729,10 @@ def _solve(kind: str, A: Operator, M: Optional[Operator], b, x, W, maxit: int, e
             raise ValueError(f"expected {n} entries, got {kx.size}")
         px = vp(kx.ctypes.data)
     cap = int(min(maxit if maxit else n, n)) + 1
-    res = np.empty(cap)
+    res, res_p = ctx._res_buffer(cap)
     it = i64()
     L = ctx._L
-    tail = (i64(maxit), C.c_double(eps), res.ctypes.data_as(f64p), i64(cap), C.byref(it))
+    tail = (maxit, eps, res_p, cap, C.byref(it))
     if W is not None:
         if _is_torch(W):
             if W.dim() != 2 or W.shape[0] != n or W.stride(0) != 1:

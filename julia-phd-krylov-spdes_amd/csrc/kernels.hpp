@@ -32,6 +32,7 @@ struct PinnedFlags {
   int overflow;
   int respec;              // whole-solve graph built for x0 == 0 met a non-zero x0: nothing was done, replay the general one
   int x0z;                 // the initial guess of this solve was identically zero
+  long long t_entry, t_exit;  // wall_clock64() (100 MHz) at the entry kernel's start and at the hand-over (MI355_SOLVE_STATS)
   unsigned long long seq;  // whole-solve graph: the solve number, stored LAST by whoever publishes (the host spins on it)
 };
 // Per-call arguments of a solve whose entry and exit kernels are part of the replayed graph: the host fills this block
@@ -466,6 +467,10 @@ struct IcgMeta {
   double *tol;
   int *done_cur, *done_nxt, *iters;
   int maxiter_cap;             // 0: maxiter = n_i of the subdomain
+  // `Pl` = Diagonal(A): c = Pl \ r, rho = dot(c, r), beta = rho / rho_prev, u = c + beta u, alpha = rho / u'c
+  const double *dinv;          // nullptr: unpreconditioned (rho = residual^2)
+  double *rho_cur, *rho_nxt;
+  double *p_rz;                // per-block partials of r'z
 };
 __device__ __forceinline__ double icg_dom_sum(const double *part, int b0, int b1, double *sm) {
   double v = 0.0;
@@ -485,22 +490,29 @@ __global__ __launch_bounds__(NT) void k_icg_init(IcgMeta m, const double *__rest
   __shared__ double sm[NT / 64 + 1];
   const SpmvBlock bi = m.blk[blockIdx.x];
   double s = 0.0;
+  double sz = 0.0;
   for (int i = bi.r0 + threadIdx.x; i < bi.r1; i += NT) {
     const double v = rhs[i];
-    r[i] = v; u[i] = v; x[i] = 0.0;
+    const double z = m.dinv ? m.dinv[i] * v : v;
+    r[i] = v; u[i] = z; x[i] = 0.0;
     s += v * v;
+    sz += v * z;
   }
   s = block_sum(s, sm);
-  if (threadIdx.x == 0) p_rr[blockIdx.x] = s;
+  if (m.dinv) sz = block_sum(sz, sm);
+  if (threadIdx.x == 0) { p_rr[blockIdx.x] = s; if (m.dinv) m.p_rz[blockIdx.x] = sz; }
 }
 // one workgroup per subdomain: residual = ||b||, tol = reltol*residual, flags
 __global__ __launch_bounds__(NT) void k_icg_start(IcgMeta m, const double *__restrict__ p_rr, double reltol) {
   __shared__ double sm[NT / 64 + 1];
   const int d = blockIdx.x;
   const double rr = icg_dom_sum(p_rr, m.dom_b0[d], m.dom_b1[d], sm);
+  const double rz = m.dinv ? icg_dom_sum(m.p_rz, m.dom_b0[d], m.dom_b1[d], sm) : 0.0;
   if (threadIdx.x == 0) {
     const double res = sqrt(rr);
     m.res_cur[d] = res; m.res_nxt[d] = res;
+    const double rho = m.dinv ? rz : res * res;
+    m.rho_cur[d] = rho; m.rho_nxt[d] = rho;
     m.tol[d] = reltol * res;
     m.iters[d] = 0;
     const int dn = res <= m.tol[d];
@@ -517,18 +529,21 @@ __global__ __launch_bounds__(NT) void k_icg_update(IcgMeta m, const double *__re
   if (m.done_nxt[d]) { if (lead) m.done_cur[d] = 1; return; }
   const double uc = icg_dom_sum(p_uc, m.dom_b0[d], m.dom_b1[d], sm);
   const double res = m.res_nxt[d];
-  const double alpha = (res * res) / uc;
+  const double rho = m.dinv ? m.rho_nxt[d] : res * res;
+  const double alpha = rho / uc;
   const SpmvBlock bi = m.blk[b];
-  double s = 0.0;
+  double s = 0.0, sz = 0.0;
   for (int i = bi.r0 + threadIdx.x; i < bi.r1; i += NT) {
     x[i] = x[i] + alpha * u[i];
     const double ri = r[i] - alpha * c[i];
     r[i] = ri;
     s += ri * ri;
+    if (m.dinv) sz += ri * (m.dinv[i] * ri);
   }
   s = block_sum(s, sm);
-  if (threadIdx.x == 0) p_rr[b] = s;
-  if (lead) { m.res_cur[d] = res; m.done_cur[d] = 0; }
+  if (m.dinv) sz = block_sum(sz, sm);
+  if (threadIdx.x == 0) { p_rr[b] = s; if (m.dinv) m.p_rz[b] = sz; }
+  if (lead) { m.res_cur[d] = res; m.rho_cur[d] = rho; m.done_cur[d] = 0; }
 }
 // residual = ||r||; beta = residual^2 / prev_residual^2; u = r + beta u; iteration count and stop test
 __global__ __launch_bounds__(NT) void k_icg_direction(IcgMeta m, const double *__restrict__ p_rr,
@@ -539,13 +554,18 @@ __global__ __launch_bounds__(NT) void k_icg_direction(IcgMeta m, const double *_
   if (m.done_cur[d]) return;
   const double rr = icg_dom_sum(p_rr, m.dom_b0[d], m.dom_b1[d], sm);
   const double res = sqrt(rr), prev = m.res_cur[d];
-  const double beta = (res * res) / (prev * prev);
+  double beta = (res * res) / (prev * prev), rho = 0.0;
+  if (m.dinv) {
+    rho = icg_dom_sum(m.p_rz, m.dom_b0[d], m.dom_b1[d], sm);
+    beta = rho / m.rho_cur[d];
+  }
   const SpmvBlock bi = m.blk[b];
-  for (int i = bi.r0 + threadIdx.x; i < bi.r1; i += NT) u[i] = r[i] + beta * u[i];
+  for (int i = bi.r0 + threadIdx.x; i < bi.r1; i += NT) u[i] = (m.dinv ? m.dinv[i] * r[i] : r[i]) + beta * u[i];
   if (b == m.dom_b0[d] && threadIdx.x == 0) {
     const int it = m.iters[d] + 1;
     m.iters[d] = it;
     m.res_nxt[d] = res;
+    if (m.dinv) m.rho_nxt[d] = rho;
     const int maxiter = m.maxiter_cap > 0 ? m.maxiter_cap : n_i[d];
     m.done_nxt[d] = (res <= m.tol[d]) || (it >= maxiter);
   }
@@ -566,12 +586,15 @@ struct IcgDomState {
 };
 struct IcgPiece {
   int lo, hi, dom, slot;  // rows [lo, hi) of subdomain dom; partial slot (consecutive within the subdomain)
+  int b0, b1, lead, pad;  // row-block range of the subdomain (partials of u'c); first piece of the subdomain
+};
+struct IcgBlkInfo {       // per SpMV row block, next to its SpmvBlock record: one load instead of a chain of index lookups
+  int dom, p0, np, lead;  // subdomain; its partial-slot range (pieces); first block of the subdomain
+  int maxit, pad0, pad1, pad2;
 };
 struct IcgFold {
   const SpmvBlock *blk;
-  const int *blk_dom, *dom_b0, *dom_b1;  // subdomain of every row block; row-block range of every subdomain
-  const int *dom_p0, *dom_p1;            // partial-slot range of every subdomain (pieces)
-  const int *n_i;                        // interior size of every subdomain (maxiter)
+  const IcgBlkInfo *binfo;
   IcgDomState *cur, *nxt;
   double *ur0, *ur1;                     // interleaved (u, z) pairs, two buffers (parity of the subdomain's `it`)
   double *c, *r;
@@ -586,10 +609,15 @@ __global__ __launch_bounds__(NT, 8) void k_icg_spmv(int nblocks, IcgFold m, cons
   __shared__ double sm2[2 * (NT / 64)];
   const int b = spmv_block_of(nblocks);
   if (b >= nblocks) return;
-  const int d = m.blk_dom[b];
+  const IcgBlkInfo inf = m.binfo[b];
+  const SpmvBlock bi = m.blk[b];
+  const int d = inf.dom;
+  // the subdomain's partials are requested together with its scalars (both addresses come from the block's own record)
+  const int p0 = inf.p0, np = inf.np;
+  double rr = (int)threadIdx.x < np ? m.part_rr[p0 + threadIdx.x] : 0.0;
+  double rz = (m.dinv && (int)threadIdx.x < np) ? m.part_rz[p0 + threadIdx.x] : 0.0;
   const IcgDomState S = m.cur[d];
   if (S.done) return;
-  const SpmvBlock bi = m.blk[b];
   const int r0 = bi.r0, r1 = bi.r1, k0 = bi.k0, nnz = bi.k1 - k0;
   const double2 *ur_old = reinterpret_cast<const double2 *>((S.it & 1) ? m.ur1 : m.ur0);
   double2 *ur_new = reinterpret_cast<double2 *>((S.it & 1) ? m.ur0 : m.ur1);
@@ -608,15 +636,12 @@ __global__ __launch_bounds__(NT, 8) void k_icg_spmv(int nblocks, IcgFold m, cons
   double2 o0 = make_double2(0.0, 0.0);
   if (ra < r1) { a0 = rowptr[ra] - k0; e0 = rowptr[ra + 1] - k0; o0 = ur_old[ra]; }
   // ---- scalars of this subdomain (identical in all of its workgroups): at most NT pieces per subdomain
-  const int p0 = m.dom_p0[d], np = m.dom_p1[d] - p0;
-  double rr = (int)threadIdx.x < np ? m.part_rr[p0 + threadIdx.x] : 0.0;
-  double rz = (m.dinv && (int)threadIdx.x < np) ? m.part_rz[p0 + threadIdx.x] : 0.0;
   block_sum2_t<NT>(rr, rz, sm2);
   const double res = sqrt(rr);
   const double rho = m.dinv ? rz : res * res;          // IterativeSolvers: residual^2, resp. dot(c, r) with Pl
   const double tol = S.it == 0 ? m.reltol * res : S.tol;
-  const bool stop = !(res > tol) || S.it >= m.n_i[d];  // `while residual > tol && iteration < maxiter`, maxiter = size(A, 2)
-  if (b == m.dom_b0[d] && threadIdx.x == 0) {
+  const bool stop = !(res > tol) || S.it >= inf.maxit;  // `while residual > tol && iteration < maxiter`, maxiter = size(A, 2)
+  if (inf.lead && threadIdx.x == 0) {
     IcgDomState N;
     N.rho_prev = rho; N.tol = tol; N.res = res; N.it = S.it + (stop ? 0 : 1); N.done = stop;
     m.nxt[d] = N;
@@ -674,7 +699,7 @@ __global__ __launch_bounds__(NT) void k_icg_update_blk(IcgFold m, const IcgPiece
   if (pc.hi <= pc.lo) return;
   const int d = pc.dom;
   const IcgDomState N = m.nxt[d];
-  const bool lead = pc.slot == m.dom_p0[d] && threadIdx.x == 0;
+  const bool lead = pc.lead && threadIdx.x == 0;
   if (N.done) {
     if (lead) { IcgDomState C = N; m.cur[d] = C; }
     return;
@@ -688,7 +713,7 @@ __global__ __launch_bounds__(NT) void k_icg_update_blk(IcgFold m, const IcgPiece
     uv[k] = ok ? ur[rw].x : 0.0; cv[k] = ok ? m.c[rw] : 0.0; xv[k] = ok ? x[rw] : 0.0; rv[k] = ok ? m.r[rw] : 0.0;
     dv[k] = ok && m.dinv ? m.dinv[rw] : 1.0;
   }
-  const double uc = icg_dom_sum(m.part_uc, m.dom_b0[d], m.dom_b1[d], sm);
+  const double uc = icg_dom_sum(m.part_uc, pc.b0, pc.b1, sm);
   const double alpha = N.rho_prev / uc;                 // nxt.rho_prev holds this iteration's rho
   if (lead) { IcgDomState C = N; C.done = 0; m.cur[d] = C; }
   double srr = 0.0, srz = 0.0;
@@ -727,7 +752,7 @@ __global__ __launch_bounds__(NT) void k_icg_fold_init(IcgFold m, const IcgPiece 
   srz = block_sum(srz, sm);
   if (threadIdx.x == 0) {
     m.part_rr[pc.slot] = srr; m.part_rz[pc.slot] = srz;
-    if (pc.slot == m.dom_p0[pc.dom]) {
+    if (pc.lead) {
       IcgDomState C;
       C.rho_prev = 1.0; C.tol = 0.0; C.res = 0.0; C.it = 0; C.done = 0;
       m.cur[pc.dom] = C; m.nxt[pc.dom] = C;
@@ -1058,7 +1083,11 @@ struct PcgFold {
   // so that the host is released before this launch and the graph's tail have drained
   const SolveArgs *exit_args;
   PinnedFlags *exit_flags;
+  long long *dbg;           // MI355_FOLD_DEBUG: wall-clock stamps of workgroup dbg_wg, 8 per launch (tools/fold_stamps.py)
+  int dbg_wg;
 };
+#define MI_FSTAMP(i) \
+  do { if (f.dbg && (int)blockIdx.x == f.dbg_wg && threadIdx.x == 0) f.dbg[dbg_row * 8 + (i)] = wall_clock64(); } while (0)
 __device__ __forceinline__ double slot_sum(const double *slots, int g, int W) {
   double s = 0.0;
   if (W == 4) {
@@ -1098,6 +1127,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   const long long it0 = st->it, it_nxt0 = st->it_nxt, maxit = st->maxit, cap = st->res_cap;
   const double tol = st->tol, rTz0 = st->rTz, old = st->rTz_prev;
   const bool first1 = PHASE == 1 && it_nxt0 == 0;  // very first launch of a solve: r_0 comes from the Γ-ordered vector, p = 0
+  const int dbg_row = (int)((PHASE == 1 ? 2 * it_nxt0 : 2 * it0 + 1) & 63);
+  MI_FSTAMP(0);
   double pa = 0.0, pb = 0.0;
   for (int i0 = threadIdx.x; i0 < f.n_in; i0 += 8 * NTH) {  // up to eight partials in flight per thread, added in order
     double ta[8], tb[8];
@@ -1165,6 +1196,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
 #if MI355_OPERAND_FIRST
   if (t.active) rows.begin(m, t);  // matrix stream in flight from here on: issued AFTER the prologue's loads (results return in issue order)
 #endif
+  MI_FSTAMP(1);   // all prologue loads and the first matrix group issued
   // ---- scalars
   double coef;  // alpha (PHASE 1) or beta (PHASE 0)
   if (PHASE == 1) {
@@ -1205,6 +1237,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
         if (threadIdx.x == 0) {
           PinnedFlags *fl = f.exit_flags;
           fl->it = it_new; fl->done = 1; fl->overflow = it_new > cap; fl->respec = 0; fl->x0z = st->x0_zero;
+          fl->t_exit = wall_clock64();
           __threadfence_system();
           __hip_atomic_store(&fl->seq, q.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -1213,6 +1246,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     }
   }
 
+  MI_FSTAMP(2);   // partial sums reduced: alpha / beta known
   // ---- operand of this GEMV into LDS; rows of this tile: value for the epilogue dot, owners' stores
 #pragma unroll
   for (int q = 0; q < FOLD_CPT; ++q) {
@@ -1256,7 +1290,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   // owner stores of p / r) and stops here; its contribution rows and partial dot come from the owning rank through the
   // all-reduce that follows the launch (its own entries stay zero).
   if (PHASE == 0 && !t.active) return;  // (the host only shards the S launch; the ΠS launch needs all tiles)
+  MI_FSTAMP(3);   // operand staged
   rows.panel(xs, 0, t.ld);
+  MI_FSTAMP(4);   // stream consumed
   double sum[RPW];
   rows.finish(sum);
   const int w = threadIdx.x >> 6;
@@ -1279,6 +1315,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   }
   if (PHASE == 1 && o_q >= 0 && o_own) f.x[o_g] = o_x + coef * o_a;  // x + alpha*p (cg.jl:97), off the critical path
   __syncthreads();
+  MI_FSTAMP(5);   // results scattered
   if (PHASE == 0 && f.part_rows) {
     // multi-GPU, sharded S: one product per ROW at its local position instead of one partial per tile — a layout that
     // does not depend on how each rank tiles its blocks, so the ranks' arrays add up to the full one
@@ -1311,6 +1348,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
       else f.part_out0[blockIdx.x] = a;
     }
   }
+  MI_FSTAMP(6);
 }
 
 // y[i] = sum of the local contributions to Γ node i, in ascending subdomain order
@@ -1521,8 +1559,9 @@ __device__ __forceinline__ unsigned long long sys_load_u64(const void *p) {
   return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ __launch_bounds__(NT) void k_solve_begin_g(int n, const SolveArgs *pin, double *__restrict__ b, double *__restrict__ x,
-                                                      SolverState *st, SolveArgs *dev) {
+                                                      SolverState *st, SolveArgs *dev, PinnedFlags *flags) {
   __shared__ unsigned long long a[sizeof(SolveArgs) / 8];
+  if (blockIdx.x == 0 && threadIdx.x == 0) flags->t_entry = wall_clock64();
   static_assert(sizeof(SolveArgs) % 8 == 0 && sizeof(SolveArgs) / 8 <= 64, "SolveArgs is a block of 8-byte fields");
   if (threadIdx.x < sizeof(SolveArgs) / 8) a[threadIdx.x] = sys_load_u64((const unsigned long long *)pin + threadIdx.x);
   __syncthreads();
@@ -1564,6 +1603,7 @@ __global__ __launch_bounds__(NT) void k_solve_end_g(int n, SolverState *st, cons
   if (last && threadIdx.x == 0) {
     *end_count = 0;
     flags->it = it; flags->done = st->done; flags->overflow = st->overflow; flags->respec = 0; flags->x0z = *x0_zero;
+    flags->t_exit = wall_clock64();
     *x0_zero = 1;
     __threadfence_system();
     __hip_atomic_store(&flags->seq, q.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1959,6 +1999,7 @@ __global__ __launch_bounds__(NTF) void k_entry_zero(int n, const SolveArgs *pin,
                                                     double *__restrict__ r, SolverState *st, SolveArgs *dev, PinnedFlags *flags) {
   __shared__ unsigned long long a[sizeof(SolveArgs) / 8];
   __shared__ double sm[NTF / 64 + 1];
+  if (threadIdx.x == 0) flags->t_entry = wall_clock64();
   if (threadIdx.x < sizeof(SolveArgs) / 8) a[threadIdx.x] = sys_load_u64((const unsigned long long *)pin + threadIdx.x);
   __syncthreads();
   const SolveArgs &q = *reinterpret_cast<const SolveArgs *>(a);

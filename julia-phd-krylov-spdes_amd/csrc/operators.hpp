@@ -565,13 +565,15 @@ struct InteriorCg {
   double *graph_x = nullptr;
   IcgMeta meta{};
   long long total_iterations = 0;  // statistics: iterations of the slowest subdomain, summed over solves
-  // 2-launch form (k_icg_spmv / k_icg_update_blk): default; MI355_ICG_UNFUSED=1 keeps the 3-launch loop
-  bool folded = true;
+  // 2-launch form (k_icg_spmv / k_icg_update_blk), MI355_ICG_FUSED=1: measured SLOWER than the 3-launch loop at 1 M DoF
+  // (62.7 vs 45.6 us per iteration: the on-the-fly direction doubles the gathered bytes of a 7 M-non-zero SpMV), so
+  // it is an opt-in kept for its tests; DESIGN.md §5
+  bool folded = false;
   IcgFold fm{};
   DevBuf<IcgPiece> pieces;
   DevBuf<IcgDomState> dst;   // cur[ndl], nxt[ndl]
-  DevBuf<double> ur, part_rz, dinv;
-  DevBuf<int> dom_p0, dom_p1;
+  DevBuf<double> ur, part_rz, dinv, rho;
+  DevBuf<IcgBlkInfo> binfo;
   IcgDomState *dst_host = nullptr;
   std::vector<int> ioff_h;
   int npieces_grid = 0;
@@ -598,8 +600,17 @@ struct InteriorCg {
     done_cur.alloc(ndl + 1); done_nxt.alloc(ndl + 1); iters.alloc(ndl + 1);
     MI_HIP(hipHostMalloc((void **)&done_host, sizeof(int) * (ndl + 1)));
     chunk = std::max(1, env_int("MI355_ICG_CHUNK", 64));
-    meta = IcgMeta{A.blk.p, blk_dom.p, dom_b0.p, dom_b1.p, res_cur.p, res_nxt.p, tol.p, done_cur.p, done_nxt.p, iters.p, 0};
-    folded = !env_int("MI355_ICG_UNFUSED", 0);
+    rho.alloc(2 * (size_t)ndl + 2); part_rz.alloc((size_t)A.nblocks + 1);
+    meta = IcgMeta{A.blk.p, blk_dom.p, dom_b0.p, dom_b1.p, res_cur.p, res_nxt.p, tol.p, done_cur.p, done_nxt.p, iters.p, 0,
+                   nullptr, rho.p, rho.p + ndl + 1, part_rz.p};
+    {  // 1 / diagonal of A_II (for the optional Jacobi `Pl`)
+      std::vector<double> dg((size_t)n + 1, 1.0);
+      for (int r_ = 0; r_ < a.n_rows; ++r_)
+        for (int k = a.rowptr[r_]; k < a.rowptr[r_ + 1]; ++k)
+          if (a.col[k] == r_) dg[r_] = 1.0 / a.val[k];
+      dinv.upload(dg, ctx->stream);
+    }
+    folded = env_int("MI355_ICG_FUSED", 0) != 0;
     ioff_h = ioff;
     if (folded) build_fold(a, b0, b1);
   }
@@ -625,7 +636,8 @@ struct InteriorCg {
         const int cnt = (hi - lo + rows_per - 1) / rows_per;
         for (int k = 0; k < cnt; ++k) {
           const int a0 = lo + (int)((long long)(hi - lo) * k / cnt), a1 = lo + (int)((long long)(hi - lo) * (k + 1) / cnt);
-          per_xcd[x].push_back(IcgPiece{a0, a1, d, slot++});
+          per_xcd[x].push_back(IcgPiece{a0, a1, d, slot, b0[d], b1[d], slot == p0[d] ? 1 : 0, 0});
+          ++slot;
         }
       }
       p1[d] = slot;
@@ -634,25 +646,31 @@ struct InteriorCg {
     if (!ok) { folded = false; return; }
     size_t mx = 0;
     for (auto &v : per_xcd) mx = std::max(mx, v.size());
-    std::vector<IcgPiece> tab(8 * std::max<size_t>(1, mx), IcgPiece{0, 0, 0, 0});
+    std::vector<IcgPiece> tab(8 * std::max<size_t>(1, mx), IcgPiece{0, 0, 0, 0, 0, 0, 0, 0});
     for (int x = 0; x < 8; ++x)
       for (size_t j = 0; j < per_xcd[x].size(); ++j) tab[j * 8 + x] = per_xcd[x][j];
     npieces_grid = (int)tab.size();
     pieces.upload(tab, s);
-    dom_p0.upload(p0, s); dom_p1.upload(p1, s);
+    {
+      std::vector<int> bdh(A.nblocks), nih(ndl);
+      MI_HIP(hipStreamSynchronize(s));
+      MI_HIP(hipMemcpy(bdh.data(), blk_dom.p, sizeof(int) * A.nblocks, hipMemcpyDeviceToHost));
+      MI_HIP(hipMemcpy(nih.data(), n_i.p, sizeof(int) * ndl, hipMemcpyDeviceToHost));
+      std::vector<IcgBlkInfo> bi(A.nblocks);
+      for (int b = 0; b < A.nblocks; ++b) {
+        const int d = bdh[b];
+        bi[b] = IcgBlkInfo{d, p0[d], p1[d] - p0[d], b == b0[d] ? 1 : 0, nih[d], 0, 0, 0};
+      }
+      binfo.upload(bi, s);
+    }
     std::vector<IcgDomState> st0(2 * (size_t)ndl);
     for (auto &q : st0) { q.rho_prev = 1.0; q.tol = 0.0; q.res = 0.0; q.it = 0; q.done = 1; }   // an empty interior stays "done"
     dst.upload(st0, s);
-    ur.alloc(4 * (size_t)n + 4); part_rz.alloc((size_t)slot + 1);
+    ur.alloc(4 * (size_t)n + 4);
+    if (part_rz.n < (size_t)slot + 1) part_rz.alloc((size_t)slot + 1);
     if (p_rr.n < (size_t)slot + 1) p_rr.alloc((size_t)slot + 1);
     MI_HIP(hipHostMalloc((void **)&dst_host, sizeof(IcgDomState) * (ndl + 1)));
-    // diagonal of A_II (for the optional Jacobi `Pl`)
-    std::vector<double> dg((size_t)n + 1, 1.0);
-    for (int r = 0; r < a.n_rows; ++r)
-      for (int k = a.rowptr[r]; k < a.rowptr[r + 1]; ++k)
-        if (a.col[k] == r) dg[r] = 1.0 / a.val[k];
-    dinv.upload(dg, s);
-    fm = IcgFold{A.blk.p, blk_dom.p, dom_b0.p, dom_b1.p, dom_p0.p, dom_p1.p, n_i.p, dst.p, dst.p + ndl, ur.p, ur.p + 2 * (size_t)n,
+    fm = IcgFold{A.blk.p, binfo.p, dst.p, dst.p + ndl, ur.p, ur.p + 2 * (size_t)n,
                  c.p, r.p, p_uc.p, p_rr.p, part_rz.p, nullptr, reltol};
   }
   ~InteriorCg() {
@@ -661,14 +679,14 @@ struct InteriorCg {
     if (dst_host) (void)hipHostFree(dst_host);
   }
   void set_jacobi(bool on) {
-    if (on && !folded) raise(MI_ERR_BAD_ARG, "the diagonal interior preconditioner needs the 2-launch interior CG");
-    if (on != jacobi && graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
+    if (on != jacobi && graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }   // kernel arguments are captured
     jacobi = on;
     fm.dinv = on ? dinv.p : nullptr;
+    meta.dinv = on ? dinv.p : nullptr;
   }
   // after new values of A_II: 1 / diagonal again (device side)
   void refresh_diagonal() {
-    if (!folded || n == 0) return;
+    if (n == 0) return;
     hipLaunchKernelGGL(k_csr_inv_diag, dim3((n + NT - 1) / NT), dim3(NT), 0, ctx->stream, n, A.rowptr.p, A.col.p, A.val.p, dinv.p);
     MI_HIP(hipGetLastError());
   }

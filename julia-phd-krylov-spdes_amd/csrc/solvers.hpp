@@ -133,6 +133,7 @@ struct SolverWorkspace {
   // deflation
   DevBuf<double> W, AW, LU, mu, part_mu, gram;
   DevBuf<double> fold_mu, fold_wm;  // folded Def-PCG: per-tile partials of WtA*z, (W*mu) in local order
+  DevBuf<long long> fold_dbg;       // MI355_FOLD_DEBUG=1: 64 launches x 8 stamps of one workgroup of the folded launches
   DevBuf<double> cf_pz, cf_rr, cf_rz;  // 2-launch sparse pcg: two buffers of interleaved (p, z) pairs, per-block partials
   DevBuf<int> piv;
   int nvec_cap = 0;
@@ -147,6 +148,22 @@ struct SolverWorkspace {
   DevBuf<SolveArgs> args_dev;      // its device copy for k_solve_end_g, + the exit kernel's workgroup counter
   DevBuf<unsigned> end_count;
   unsigned long long seq = 0;
+  // MI355_SOLVE_STATS=1: every 64 whole-graph solves, the average device span (entry kernel's start .. hand-over) and the
+  // average host period between hand-overs go to stderr (period - span = host turnaround + launch latency)
+  bool stats_on = env_int("MI355_SOLVE_STATS", 0) != 0;
+  long long stat_span = 0;
+  int stat_n = 0;
+  std::chrono::steady_clock::time_point stat_t0;
+  void stat(long long span_ticks) {
+    const auto now = std::chrono::steady_clock::now();
+    if (stat_n == 0) stat_t0 = now;
+    else stat_span += span_ticks;
+    if (++stat_n == 65) {
+      const double period = std::chrono::duration<double, std::micro>(now - stat_t0).count() / 64.0;
+      std::fprintf(stderr, "[mi355 solve stats] n=%lld: device span %.2f us, host period %.2f us\n", (long long)n, stat_span * 0.01 / 64.0, period);
+      stat_n = 0; stat_span = 0;
+    }
+  }
   double *res_stage = nullptr;     // pinned landing zone for short residual histories
   hipEvent_t ev[2] = {nullptr, nullptr};
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -169,6 +186,7 @@ struct SolverWorkspace {
     MI_HIP(hipHostMalloc((void **)&flags, 2 * sizeof(PinnedFlags)));
     std::memset(flags, 0, 2 * sizeof(PinnedFlags));
     MI_HIP(hipHostMalloc((void **)&args, sizeof(SolveArgs)));
+    if (env_int("MI355_FOLD_DEBUG", 0)) { fold_dbg.alloc(512); MI_HIP(hipMemset(fold_dbg.p, 0, 512 * sizeof(long long))); }
     args_dev.alloc(1); end_count.alloc(1);
     MI_HIP(hipMemset(end_count.p, 0, sizeof(unsigned)));
     MI_HIP(hipHostMalloc((void **)&res_stage, RES_STAGE * sizeof(double)));
@@ -304,6 +322,7 @@ struct Krylov {
     f.nvec = nvec; f.n_gamma = n;
     if (nvec > 0) { f.AW = ws.AW.p; f.part_mu = ws.fold_mu.p; f.wm_loc = ws.fold_wm.p; }
     if (capture_whole && phase == 0) { f.exit_args = ws.args_dev.p; f.exit_flags = &ws.flags[0]; }
+    if (ws.fold_dbg.p) { f.dbg = ws.fold_dbg.p; f.dbg_wg = env_int("MI355_FOLD_DEBUG_WG", 0); }
     f.n_in = phase ? (f.part_rows ? Ad->maps.nloc : Ad->ntiles) : Md->ntiles;
     const bool red = Ad->reduce_over_ranks;  // the S launch's outputs are summed over the ranks before the ΠS launch reads them
     if (phase) {  // ΠS launch: reads S contributions + partial p'Ap, writes ΠS contributions + partial r'r, r'z
@@ -521,6 +540,8 @@ struct Krylov {
 
   // chunk > 0: `chunk` iterations; chunk < 0: set-up tail + (-chunk) iterations; whole: the entry kernel in front of
   // and the exit kernel behind them (arguments through ws.args), so that a solve is ONE replay.
+  // (Splitting a whole-solve graph into a short head and the rest, so that the GPU starts while the host still enqueues,
+  // was measured: 432 vs 427 us per solve — one replay is cheaper than two.)
   hipGraphExec_t graph(int chunk, int whole = 0) {
     GraphKey key{A, M, nvec, chunk, eig.tag * 8 + (fused ? 1 : 0) + (fold ? 2 : 0) + (csrfold() ? 4 : 0) + 1024 * whole};  // the loop form is part of the graph
     auto it = ws.graphs.find(key);
@@ -536,7 +557,7 @@ struct Krylov {
         MI_HIP(hipGetLastError());
       } else {
         if (whole) {
-          hipLaunchKernelGGL(k_solve_begin_g, dim3(g), dim3(NT), 0, s, n, ws.args, ws.b, ws.x, ws.st, ws.args_dev.p);
+          hipLaunchKernelGGL(k_solve_begin_g, dim3(g), dim3(NT), 0, s, n, ws.args, ws.b, ws.x, ws.st, ws.args_dev.p, &ws.flags[0]);
           MI_HIP(hipGetLastError());
         }
         if (chunk < 0) setup_tail();
@@ -740,6 +761,20 @@ struct Krylov {
           wait_seq(seq2);
         }
         if (fold) ws.zero_x0[pk] = ws.flags[0].x0z != 0;
+        if (ws.stats_on) ws.stat(ws.flags[0].t_exit - ws.flags[0].t_entry);
+        if (ws.fold_dbg.p && fold) {   // stamps of the solve that has just finished (100 MHz ticks -> us since the first one)
+          std::vector<long long> h(512);
+          MI_HIP(hipStreamSynchronize(s));
+          MI_HIP(hipMemcpy(h.data(), ws.fold_dbg.p, 512 * sizeof(long long), hipMemcpyDeviceToHost));
+          const long long t0 = h[0] ? h[0] : ws.flags[0].t_entry;
+          std::fprintf(stderr, "[fold stamps] wg %d, entry kernel at %.2f us\n", env_int("MI355_FOLD_DEBUG_WG", 0), (ws.flags[0].t_entry - t0) * 0.01);
+          for (int r = 0; r < 64 && h[r * 8]; ++r) {
+            std::fprintf(stderr, "  launch %2d:", r);
+            for (int k = 0; k < 7; ++k) std::fprintf(stderr, " %8.2f", h[r * 8 + k] ? (h[r * 8 + k] - t0) * 0.01 : -1.0);
+            std::fprintf(stderr, "\n");
+          }
+          MI_HIP(hipMemset(ws.fold_dbg.p, 0, 512 * sizeof(long long)));
+        }
       } else {
         MI_HIP(hipGraphLaunch(g0, s));
         enqueue_results(0);

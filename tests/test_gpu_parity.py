@@ -492,8 +492,8 @@ def test_whole_solve_graph_entry_exit_and_speculation(pkg, ctx, orc, toy, monkey
 
 
 def test_interior_cg_two_launch_form_and_diagonal_precond(pkg, ctx, orc, fem, ragged, monkeypatch):
-    """The interior CG runs 2 launches per iteration (k_icg_spmv / k_icg_update_blk: the direction is formed on the fly from
-    gathered (u, z) pairs); MI355_ICG_UNFUSED=1 keeps round 1's 3-launch loop. Both restate the same iteration
+    """MI355_ICG_FUSED=1 runs the interior CG in 2 launches per iteration (k_icg_spmv / k_icg_update_blk: the direction is
+    formed on the fly from gathered (u, z) pairs; slower than the 3-launch default at 1 M DoF, kept as an opt-in). Both restate the same iteration
     (IterativeSolvers.cg, EPDD.jl:648-650), so they agree to the order of the interior tolerance, with the same bar as
     against the oracle. `interior_precond("diagonal")` is the `precond` keyword with Pl = Diagonal(A_IIdd): same answer
     to the interior tolerance, fewer iterations; new block values refresh the diagonal."""
@@ -503,10 +503,10 @@ def test_interior_cg_two_launch_form_and_diagonal_precond(pkg, ctx, orc, fem, ra
     v = np.random.default_rng(22).standard_normal(n)
     args = (ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, P.sub.node_Γ_cnt, None)
     for reltol in (1e-9, 1e-5):
-        S2 = api.MatrixFreeLocalSchurs(*args, reltol=reltol)
-        monkeypatch.setenv("MI355_ICG_UNFUSED", "1")
         S3 = api.MatrixFreeLocalSchurs(*args, reltol=reltol)
-        monkeypatch.delenv("MI355_ICG_UNFUSED")
+        monkeypatch.setenv("MI355_ICG_FUSED", "1")
+        S2 = api.MatrixFreeLocalSchurs(*args, reltol=reltol)
+        monkeypatch.delenv("MI355_ICG_FUSED")
         So = orc.apply_local_schurs_matfree_operator(P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, P.sub.gather_idx, n,
                                                      orc.interior_cg_solvers(P.A_IIdd, reltol))
         want = So * v
@@ -515,15 +515,18 @@ def test_interior_cg_two_launch_form_and_diagonal_precond(pkg, ctx, orc, fem, ra
         assert np.allclose(y2, want, rtol=0, atol=bar) and np.allclose(y3, want, rtol=0, atol=bar)
         assert np.array_equal(S2 * v, y2)                                  # replays are deterministic
     exact = api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt) * v
-    Sp, Sj = api.MatrixFreeLocalSchurs(*args), api.MatrixFreeLocalSchurs(*args)
-    Sj.interior_precond("diagonal")
-    yp, yj = Sp * v, Sj * v
-    assert np.allclose(yp, exact, rtol=0, atol=1e-7 * np.abs(exact).max())
-    assert np.allclose(yj, exact, rtol=0, atol=1e-7 * np.abs(exact).max())
-    assert 0 < Sj.interior_iterations() <= Sp.interior_iterations()
-    assert not np.any(Sj * np.zeros(n))
-    Sj.interior_precond(None)
-    assert np.array_equal(Sj * v, yp)                                      # back to the plain iteration, bit for bit
+    for fused in ("0", "1"):
+        monkeypatch.setenv("MI355_ICG_FUSED", fused)
+        Sp, Sj = api.MatrixFreeLocalSchurs(*args), api.MatrixFreeLocalSchurs(*args)
+        monkeypatch.delenv("MI355_ICG_FUSED")
+        Sj.interior_precond("diagonal")
+        yp, yj = Sp * v, Sj * v
+        assert np.allclose(yp, exact, rtol=0, atol=1e-7 * np.abs(exact).max())
+        assert np.allclose(yj, exact, rtol=0, atol=1e-7 * np.abs(exact).max())
+        assert 0 < Sj.interior_iterations() <= Sp.interior_iterations()
+        assert not np.any(Sj * np.zeros(n))
+        Sj.interior_precond(None)
+        assert np.array_equal(Sj * v, yp)                                  # back to the plain iteration, bit for bit
     with pytest.raises(pkg.api.MiError):
         api.MatrixFreeLocalSchurs(*args[:-1], P.solvers).interior_precond("diagonal")   # host-callback interior solve: nothing to precondition
     # global-Schur form of the same solve (EPDD.jl:596-625)

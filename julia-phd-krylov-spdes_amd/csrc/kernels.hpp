@@ -1108,13 +1108,21 @@ template <int RPW, int PHASE, int FOLD_CPT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f) {
   constexpr int NTH = 64 * WAVES, NR = WAVES * RPW;  // threads and rows per workgroup
   SolverState *st = f.st;
-  if (st->done) return;
+  // The tile record and the state block are requested together, before the stop flag is looked at (one memory round trip
+  // instead of two at the top of every launch; the empty asm takes them all as inputs — without it the compiler sinks
+  // every load but `done` below the early exit).
+  const GemvTile t = m.tiles[blockIdx.x];
+  const int done0 = st->done;
+  const long long it0 = st->it, it_nxt0 = st->it_nxt, maxit = st->maxit, cap = st->res_cap;
+  const double tol = st->tol, rTz0 = st->rTz, old = st->rTz_prev;
+  asm volatile("" ::"s"(t.mat_off), "s"(t.n), "s"(t.ld), "s"(t.loc_off), "s"(t.row0), "s"(t.active), "s"(t.nrows), "s"(it0),
+               "s"(it_nxt0), "s"(maxit), "s"(cap), "s"(tol), "s"(rTz0), "s"(old), "s"(done0));
+  if (done0) return;
   __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
   __shared__ double sm[2 * (NTH / 64)];
   __shared__ double rowv[NR], rowc0[NR], rowc1[NR];
   __shared__ double rowy[NR];   // deflation: the rows' z-contributions
   __shared__ int rowg[NR];      //            and their Γ indices
-  const GemvTile t = m.tiles[blockIdx.x];
   const int off = t.loc_off, W = f.W, n = t.n;
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
   if (threadIdx.x < NR) { rowc0[threadIdx.x] = 0.0; rowv[threadIdx.x] = 0.0; rowy[threadIdx.x] = 0.0; rowg[threadIdx.x] = 0; }  // visible after the barrier of the sums
@@ -1124,8 +1132,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
 #endif
 
   // ---- every load of the prologue is issued before the first barrier (one memory round trip), all contiguous
-  const long long it0 = st->it, it_nxt0 = st->it_nxt, maxit = st->maxit, cap = st->res_cap;
-  const double tol = st->tol, rTz0 = st->rTz, old = st->rTz_prev;
   const bool first1 = PHASE == 1 && it_nxt0 == 0;  // very first launch of a solve: r_0 comes from the Γ-ordered vector, p = 0
   const int dbg_row = (int)((PHASE == 1 ? 2 * it_nxt0 : 2 * it0 + 1) & 63);
   MI_FSTAMP(0);

@@ -281,15 +281,19 @@ __global__ __launch_bounds__(NT, 8) void k_spmv_pcg(int nblocks, const SpmvBlock
                                                  const double *part_rr, const double *part_rz, int g_vec, double *pz0, double *pz1,
                                                  double *__restrict__ Ap, double *__restrict__ part_pAp, double *res_norm,
                                                  int precond) {
-  if (st->done) return;
   __shared__ __attribute__((aligned(16))) double prod[SPMV_TILE];
   __shared__ double sm[NT / 64 + 1];
   const int b = spmv_block_of(nblocks);
   const bool has = b < nblocks;
-  const SpmvBlock bi = has ? blk[b] : SpmvBlock{0, 0, 0, 0};
-  const int r0 = bi.r0, r1 = bi.r1, k0 = bi.k0, nnz = bi.k1 - k0;
+  // block record, state block and stop flag in one memory round trip (the empty asm keeps the compiler from sinking the
+  // loads below the early exit)
+  const SpmvBlock bi = blk[has ? b : 0];
+  const int done0 = st->done;
   const long long it0 = st->it, maxit = st->maxit, cap = st->res_cap;
   const double tol = st->tol, old = precond ? st->rTz_prev : st->rTr_prev;
+  asm volatile("" ::"s"(bi.r0), "s"(bi.r1), "s"(bi.k0), "s"(bi.k1), "s"(done0), "s"(it0), "s"(maxit), "s"(cap), "s"(tol), "s"(old));
+  if (done0) return;
+  const int r0 = has ? bi.r0 : 0, r1 = has ? bi.r1 : 0, k0 = has ? bi.k0 : 0, nnz = has ? bi.k1 - bi.k0 : 0;
   const double2 *pz_old = reinterpret_cast<const double2 *>((it0 & 1) ? pz1 : pz0);
   double2 *pz_new = reinterpret_cast<double2 *>((it0 & 1) ? pz0 : pz1);
   // everything that does not depend on beta is requested before the reduction: this thread's non-zeros (SPMV_TILE / NT
@@ -379,13 +383,16 @@ __global__ __launch_bounds__(NT) void k_update_xr_blk(const int *__restrict__ xc
                                                       double *__restrict__ x, double *__restrict__ r,
                                                       const double *__restrict__ dinv, int diag, int precond,
                                                       double *__restrict__ part_rr, double *__restrict__ part_rz) {
-  if (st->done) return;
   __shared__ double sm[NT / 64 + 1];
   const int xc = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
   const long long R0 = xcd_row[xc], R1 = xcd_row[xc + 1];
-  const int lo = (int)(R0 + (R1 - R0) * j / nj), hi = (int)(R0 + (R1 - R0) * (j + 1) / nj);
+  const int done0 = st->done;
   const long long it_n = st->it_nxt;
-  const double num = precond ? st->rTz : st->rTr, rTr0 = st->rTr, rTz0 = st->rTz;
+  const double rTr0 = st->rTr, rTz0 = st->rTz;
+  asm volatile("" ::"s"(R0), "s"(R1), "s"(done0), "s"(it_n), "s"(rTr0), "s"(rTz0));   // one round trip, then the exit test
+  if (done0) return;
+  const int lo = (int)(R0 + (R1 - R0) * j / nj), hi = (int)(R0 + (R1 - R0) * (j + 1) / nj);
+  const double num = precond ? rTz0 : rTr0;
   double2 *pz = reinterpret_cast<double2 *>((it_n & 1) ? pz1 : pz0);     // the pairs k_spmv_pcg has just written p into
   // the first four rows of this thread: loads ahead of the reduction
   double pv[4], av[4], xv[4], rv[4], dv[4];
@@ -879,12 +886,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_batched(DenseMeta m, const 
                                                              double *__restrict__ yslots, const int *done,
                                                              const int *zero_x) {
   constexpr int NTH = 64 * WAVES;
-  if (done && *done) return;
-  __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
+  // tile record and both flags in ONE memory round trip (tested one after the other they cost three, 1.2-2 us each)
   const GemvTile t = m.tiles[blockIdx.x];
+  const int done0 = done ? *done : 0, zero0 = zero_x ? *zero_x : 0;
+  asm volatile("" ::"s"(t.mat_off), "s"(t.n), "s"(t.ld), "s"(t.loc_off), "s"(t.row0), "s"(t.active), "s"(done0), "s"(zero0));
+  if (done0) return;
+  __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
   if (!t.active) return;
   const int off = t.loc_off, n = t.n;
-  if (zero_x && *zero_x) {  // x is identically zero (set-up of a solve from x0 = 0): the products are +0, nothing to stream
+  if (zero0) {  // x is identically zero (set-up of a solve from x0 = 0): the products are +0, nothing to stream
     const int row_base = t.row0 + (threadIdx.x >> 6) * RPW;
     if ((threadIdx.x & 63) == 0)
       for (int k = 0; k < RPW; ++k)
@@ -1664,8 +1674,8 @@ __device__ __forceinline__ double block_sum_f(double v, double *sm) { return blo
 template <int EPT>
 __global__ __launch_bounds__(NTF) void k_fused_xr(int n, SolverState *st, AsmView vAp, const double *__restrict__ p,
                                                   double *__restrict__ x, double *__restrict__ r, int precond) {
-  if (st->done) return;
   __shared__ double sm[NTF / 64 + 1];
+  const int done0 = st->done;   // tested after the operands have been requested: one memory round trip, not two
   const double rTr0 = st->rTr, rTz0 = st->rTz;
   double pe[EPT], ae[EPT], xe[EPT], re[EPT];
 #pragma unroll
@@ -1674,6 +1684,8 @@ __global__ __launch_bounds__(NTF) void k_fused_xr(int n, SolverState *st, AsmVie
     pe[k] = ae[k] = xe[k] = re[k] = 0.0;
     if (e < n) { ae[k] = view_load(vAp, e); pe[k] = p[e]; xe[k] = x[e]; re[k] = r[e]; }
   }
+  asm volatile("" ::"s"(done0), "v"(pe[0]), "v"(ae[0]), "v"(xe[0]), "v"(re[0]));
+  if (done0) return;
   double s = 0.0;
 #pragma unroll
   for (int k = 0; k < EPT; ++k) s += pe[k] * ae[k];
@@ -1761,27 +1773,41 @@ __global__ __launch_bounds__(1024) void k_defl_mu(const SolverState *st, int nve
                                                   const double *__restrict__ W, long long n_gamma, int nloc,
                                                   const int *__restrict__ gidx, double *__restrict__ wm_loc,
                                                   double *__restrict__ mu_out) {
-  if (st->done) return;
+  // One memory round trip for everything whose address is known at launch (stop flag, LU factors, pivots, Γ index, the
+  // first batch of partials), a second one for the W entries behind the Γ index: the kernel is nothing but latency.
   __shared__ double lu_s[64 * 64];
   __shared__ int piv_s[64];
   __shared__ double mu_s[64];
-  for (int i = threadIdx.x; i < nvec * nvec; i += 1024) lu_s[i] = LU[i];
-  if ((int)threadIdx.x < nvec) piv_s[threadIdx.x] = piv[threadIdx.x];
-  // W entries of this thread's local position: independent of mu, requested before the solve
+  const int done0 = st->done;
+  double lu_r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int i = (int)threadIdx.x + 1024 * k; lu_r[k] = i < nvec * nvec ? LU[i] : 0.0; }
+  const int piv_r = (int)threadIdx.x < nvec ? piv[threadIdx.x] : 0;
   const int loc = blockIdx.x * 1024 + threadIdx.x;
   const long long g = loc < nloc ? gidx[loc] : 0;
-  double w0[20];                                        // the first 20 columns of W at g: in flight during the sums and the solve
-#pragma unroll
-  for (int u = 0; u < 20; ++u) w0[u] = (u < nvec && loc < nloc) ? W[(long long)u * n_gamma + g] : 0.0;
   // rhs[v] = sum over tiles: TPV = 1024 / (nvec rounded up to a power of two) threads per vector, every thread's
   // partials requested in one batch, then a TPV-lane shuffle tree (fixed order: deterministic)
   int vpad = 1;
   while (vpad < nvec) vpad <<= 1;
   const int tpv = 1024 / vpad;                          // 16 .. 1024, a power of two
   const int v = threadIdx.x / tpv, l16 = threadIdx.x % tpv;
+  double a0[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a0[k] = (v < nvec && l16 + tpv * k < ntiles) ? part_mu[(long long)v * ntiles + l16 + tpv * k] : 0.0;
+  asm volatile("" ::"s"(done0));
+  if (done0) return;
+  // W entries of this thread's local position: independent of mu, in flight during the sums and the solve
+  double w0[20];                                        // the first 20 columns of W at g
+#pragma unroll
+  for (int u = 0; u < 20; ++u) w0[u] = (u < nvec && loc < nloc) ? W[(long long)u * n_gamma + g] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int i = (int)threadIdx.x + 1024 * k; if (i < nvec * nvec) lu_s[i] = lu_r[k]; }
+  if ((int)threadIdx.x < nvec) piv_s[threadIdx.x] = piv_r;
   double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += a0[k];
   if (v < nvec)
-    for (int i0 = l16; i0 < ntiles; i0 += tpv * 16) {
+    for (int i0 = l16 + tpv * 16; i0 < ntiles; i0 += tpv * 16) {
       double a[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) a[k] = i0 + tpv * k < ntiles ? part_mu[(long long)v * ntiles + i0 + tpv * k] : 0.0;
@@ -1916,8 +1942,8 @@ __global__ __launch_bounds__(NTF) void k_fused_p(int n, SolverState *st, AsmView
 template <int EPT>
 __global__ __launch_bounds__(NTF) void k_fused_cg(int n, SolverState *st, AsmView vAp, double *__restrict__ p,
                                                   double *__restrict__ x, double *__restrict__ r, double *res_norm) {
-  if (st->done) return;
   __shared__ double sm[NTF / 64 + 1];
+  const int done0 = st->done;   // tested after the operands have been requested: one memory round trip, not two
   const double rTr0 = st->rTr, tol = st->tol;
   const long long it0 = st->it, maxit = st->maxit, cap = st->res_cap;
   double pe[EPT], ae[EPT], xe[EPT], re[EPT];
@@ -1927,6 +1953,8 @@ __global__ __launch_bounds__(NTF) void k_fused_cg(int n, SolverState *st, AsmVie
     pe[k] = ae[k] = xe[k] = re[k] = 0.0;
     if (e < n) { ae[k] = view_load(vAp, e); pe[k] = p[e]; xe[k] = x[e]; re[k] = r[e]; }
   }
+  asm volatile("" ::"s"(done0), "v"(pe[0]), "v"(ae[0]), "v"(xe[0]), "v"(re[0]));
+  if (done0) return;
   double s = 0.0;
 #pragma unroll
   for (int k = 0; k < EPT; ++k) s += pe[k] * ae[k];

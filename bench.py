@@ -191,6 +191,24 @@ def secondary_measurements(args, api, fem, ctx, S, M, b_dev, n_Γ, ndom, bytes_i
           {"workload": f"configs[1]: N=500, n={n}, nnz={A.nnz}, pcg(A,b,0,Jacobi)",
            "spmv_replayed_us": round(us, 3), "spmv_bytes": int(spmv_bytes),
            "spmv_replayed_frac": round(spmv_bytes / us / 1e3 / HBM_PEAK_GBS, 4)})
+    # ---- the reference's own partition sizes (80-500 subdomains, KarhunenLoeveDomainDecompositionHelper.jl:14-32): 160
+    # subdomains of an N = 400 mesh, n_Γ = 9417 > 8192: the generic multi-workgroup loop (tests/test_gpu_manydomains.py)
+    try:
+        mesh = fem.get_mesh(400)
+        gm = fem.draw(fem.synthetic_kl(mesh.points), np.random.default_rng(481456))[1]
+        Pm = fem.build_schur_problem(400, 16, 10, np.exp(gm), lambda x, y: -1.0 + 0 * x, lambda x, y: 0.734 + 0 * x, mesh=mesh)
+        Sm = api.LocalSchurs(ctx, Pm.Sd, Pm.sub.gather_idx, Pm.sub.node_Γ_cnt)
+        Mm = api.NeumannNeumannSchurPreconditioner(ctx, Pm.ΠSd, Pm.sub.gather_idx, Pm.sub.node_Γ_cnt)
+        bm = torch.from_numpy(Pm.b_schur).cuda()
+        zm = lambda: torch.zeros(Pm.sub.n_Γ, dtype=torch.float64, device="cuda")      # noqa: E731
+        bs, _ = Sm.bytes()
+        bn, _ = Mm.bytes()
+        entry("pcg_160_subdomains_generic_loop", lambda: api.pcg(Sm, bm, zm(), Mm, eps=args.eps),
+              lambda: api.pcg(Sm, bm, zm(), Mm, maxit=50, eps=args.eps), 50, int(bs + bn),
+              {"workload": f"N=400, 16x10 boxes, n_Γ={Pm.sub.n_Γ}, max n_Γd={max(len(a) for a in Pm.sub.gather_idx)}: "
+                           "pcg(S, b_schur, 0, ΠSnn) on the multi-workgroup loop (n_Γ > 8192)"})
+    except Exception as e:   # a side measurement must not take the headline line down
+        out["pcg_160_subdomains_generic_loop"] = {"error": f"{type(e).__name__}: {e}"}
     out["wall_s"] = round(time.perf_counter() - t_all, 1)
     return out
 

@@ -1417,6 +1417,21 @@ __global__ __launch_bounds__(NT) void k_residual(int n, const double *__restrict
     if (part_bb) part_bb[blockIdx.x] = sbb;
   }
 }
+// Start-up of the folded Schur loop when n_Γ exceeds the single-workgroup kernels (k_fused_residual<., true>): after
+// k_residual, one workgroup sums its partials and leaves the scalars exactly as that kernel does.
+__global__ __launch_bounds__(NT) void k_fold_start(SolverState *st, const double *part_rr, const double *part_bb, int g) {
+  __shared__ double sm[NT / 64 + 1];
+  const double eps = st->eps;
+  const double rr = sum_partials(part_rr, g, sm);
+  const double bb = sum_partials(part_bb, g, sm);
+  if (threadIdx.x == 0) {
+    st->rTr = rr; st->bnorm = sqrt(bb);
+    st->tol = eps * st->bnorm;
+    st->it = 0; st->it_nxt = 0; st->done = 0; st->overflow = 0;
+    st->rTz = 0.0; st->rTz_prev = 1.0; st->rTr_prev = rr;
+    st->d = 0.0; st->alpha = 0.0; st->beta = 0.0;
+  }
+}
 // Set-up: it = 1; res_norm[1] = sqrt(r'r); tol = eps*norm2(b) (cg.jl:26-32 / 81-89). eps, maxit and
 // res_cap were written into the state block by the host.
 __global__ __launch_bounds__(NT) void k_init_state(SolverState *st, const double *part_rr, const double *part_bb,

@@ -291,7 +291,10 @@ struct Krylov {
   Krylov(mi_ctx_s *c, Operator *A_, Operator *M_, int nvec_, bool generic = false, bool allow_fold = true)
       : ctx(c), A(A_), M(M_), ws(workspace(c, A_->n)), nvec(nvec_), n((int)A_->n), g(ws.g), s(c->stream),
         fused(!generic && A_->n <= FUSED_MAX_N && !env_int("MI355_NO_FUSED", 0)), fold(false) {
-    if (fused && allow_fold && M && nvec <= 64 && !env_int("MI355_NO_FOLD", 0) && !(nvec > 0 && env_int("MI355_NO_FOLD_DEFL", 0))) {
+    // (the folded launches themselves are multi-workgroup: beyond FUSED_MAX_N only the start-up differs — the
+    // reference's own partitions, 80-500 subdomains, have n_Γ of 10-40 k; undeflated solves only there)
+    const bool big_fold = !fused && !generic && nvec_ == 0 && !env_int("MI355_NO_FUSED", 0) && !env_int("MI355_NO_BIG_FOLD", 0);
+    if ((fused || big_fold) && allow_fold && M && nvec <= 64 && !env_int("MI355_NO_FOLD", 0) && !(nvec > 0 && env_int("MI355_NO_FOLD_DEFL", 0))) {
       Ad = A->as_dense(); Md = M->as_dense();
       // multi-GPU: S may be sharded (built on the maps of all subdomains, inactive tiles for the other ranks' blocks)
       // while the Neumann-Neumann blocks are replicated: the S launch is then followed by one all-reduce
@@ -487,6 +490,13 @@ struct Krylov {
       Hint(Operator *o, const int *flag) : op(o) { op->zero_hint = flag; }
       ~Hint() { op->zero_hint = nullptr; }
     };
+    if (fold && !fused) {   // n_Γ > FUSED_MAX_N: multi-workgroup residual, then the scalars of the folded loop
+      { Hint h(A, &ws.st->x0_zero); A->apply(ws.x, ws.Ap, nullptr); }
+      hipLaunchKernelGGL(k_residual, dim3(g), dim3(NT), 0, s, n, ws.b, ws.Ap, ws.r, ws.part_rr, ws.part_bb);
+      hipLaunchKernelGGL(k_fold_start, dim3(1), dim3(NT), 0, s, ws.st, ws.part_rr, ws.part_bb, g);
+      MI_HIP(hipGetLastError());
+      return;
+    }
     if (fold) {
       AsmView vAp;
       { Hint h(A, nvec == 0 ? &ws.st->x0_zero : nullptr); vAp = A->apply_view(ws.x, ws.Ap, nullptr); }  // deflated: x0 was updated by W*mu
@@ -733,7 +743,7 @@ struct Krylov {
       first = std::max<int64_t>(1, std::min<int64_t>(first, std::min<int64_t>(maxit, 1024)));
       if (ws.graphs.size() > 48) ws.drop_graphs();
       // folded loop: the entry for x0 == 0 when the previous solve with these operators had one (checked on the device)
-      bool zero_variant = whole && fold && ws.zero_x0[pk] && !env_int("MI355_NO_ZERO_ENTRY", 0);
+      bool zero_variant = whole && fold && fused && ws.zero_x0[pk] && !env_int("MI355_NO_ZERO_ENTRY", 0);
       hipGraphExec_t g0 = nullptr;
       try {
         g0 = graph(-(int)first, whole ? (zero_variant ? 2 : 1) : 0);

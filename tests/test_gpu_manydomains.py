@@ -20,7 +20,7 @@ def many(fem):
     return fem.build_schur_problem(N, px, py, np.exp(g), f_m1, u0734, mesh=mesh)
 
 
-def test_many_subdomain_schur_pcg_generic_loop(pkg, ctx, orc, many):
+def test_many_subdomain_schur_pcg_generic_loop(pkg, ctx, orc, many, monkeypatch):
     api = pkg.api
     P = many
     n, b = P.sub.n_Γ, P.b_schur
@@ -32,9 +32,19 @@ def test_many_subdomain_schur_pcg_generic_loop(pkg, ctx, orc, many):
     assert np.abs(ys - yo).max() <= 1e-13 * np.abs(yo).max()
     zs, zo = M.ldiv(v), Mo(v)
     assert np.abs(zs - zo).max() <= 1e-12 * np.abs(zo).max()
+    # pcg: the folded 2-launch loop also beyond FUSED_MAX_N (multi-workgroup start-up, then the same launches as at config 3)
+    want = orc.pcg(So, b, np.zeros(n), Mo)
     got = api.pcg(S, b, np.zeros(n), M)
-    assert_history(got, orc.pcg(So, b, np.zeros(n), Mo), So, b)
+    assert_history(got, want, So, b)
     assert np.array_equal(api.pcg(S, b, np.zeros(n), M)[0], got[0])            # replays are deterministic
+    x1 = np.random.default_rng(8).standard_normal(n)
+    assert_history(api.pcg(S, b, x1.copy(), M), orc.pcg(So, b, x1.copy(), Mo), So, b)   # non-zero initial guess
+    # ... and the generic multi-workgroup loop it replaces there (8 launches per iteration), same bar
+    monkeypatch.setenv("MI355_NO_BIG_FOLD", "1")
+    gen = api.pcg(S, b, np.zeros(n), M)
+    monkeypatch.delenv("MI355_NO_BIG_FOLD")
+    assert_history(gen, want, So, b)
+    assert abs(gen[1] - got[1]) <= 2
     # deflation with the ndom + 10 least dominant eigenvectors is Example03's set-up (Example03:206-225); any full-rank W
     # exercises the same kernels: nvec = 24 (one-wave LU solve) and nvec = 170 (generic projection kernels)
     # (the oracle's long solves dominate this test's run time on the GPU box: the second deflated solve and the recycling

@@ -27,6 +27,8 @@ def test_many_subdomain_schur_pcg_generic_loop(pkg, ctx, orc, many, monkeypatch)
     assert len(P.Sd) == 160 and n > 8192                     # beyond FUSED_MAX_N: multi-workgroup loop kernels
     S, M = gpu_ops(pkg, ctx, P)
     So, Mo = orc_ops(orc, P)
+    prev_threads = orc.set_threads(0)    # (0: query only)
+    orc.set_threads(2)                   # blocks of 130 rows: the oracle's row-parallel GEMV is all fork/join beyond a few threads
     v = np.random.default_rng(3).standard_normal(n)
     ys, yo = S * v, So * v
     assert np.abs(ys - yo).max() <= 1e-13 * np.abs(yo).max()
@@ -79,3 +81,4 @@ def test_many_subdomain_schur_pcg_generic_loop(pkg, ctx, orc, many, monkeypatch)
     import torch
     xt, itt, rest = api.pcg(S, torch.from_numpy(b).cuda(), torch.zeros(n, dtype=torch.float64, device="cuda"), M)
     assert itt == got[1] and np.array_equal(xt.cpu().numpy(), got[0])
+    orc.set_threads(prev_threads)

@@ -16,5 +16,6 @@ rm -rf /tmp/prof_kt2
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt2 -o fa -- python3 bench.py --workload fullA --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_fullA_under_rocprof.json 2> /dev/null
 cp /tmp/prof_kt2/fa_kernel_stats.csv $OUT/kernel_stats_fullA.csv
 bash tools/profile_defl.sh $TAG > $OUT/profile_defl.log 2>&1
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --many-subdomains > $OUT/bench_many_subdomains.json 2> /dev/null
 bash tools/pmc_pass.sh $TAG
 python3 tools/kstats.py $OUT/kernel_stats.csv > $OUT/kstats.txt; head -12 $OUT/kstats.txt

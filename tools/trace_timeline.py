@@ -26,9 +26,13 @@ for r in t:
     prev = e
 
 # one whole solve in the middle of the trace (k_solve_begin ... k_solve_end) and the host turnaround to the next one
-begins = [i for i, r in enumerate(rows) if "k_solve_begin" in r["Kernel_Name"]]
+is_begin = lambda r: "k_solve_begin" in r["Kernel_Name"] or "k_entry_zero" in r["Kernel_Name"]   # noqa: E731
+begins = [i for i, r in enumerate(rows) if is_begin(r)]
+# prefer a solve of the folded loop (the headline): an entry kernel directly followed by k_gemv_pcg, or by the skipped S*x0
+folded = [i for i in begins if i + 3 < len(rows) and any("k_gemv_pcg" in rows[i + k]["Kernel_Name"] for k in (1, 2, 3))]
 if len(begins) > 4:
-    b = begins[len(begins) // 2]
+    pool = folded if len(folded) > 4 else begins
+    b = pool[len(pool) // 2]
     nb = next((i for i in begins if i > b), len(rows))
     print("\none solve (k_solve_begin .. next k_solve_begin):")
     t0, prev = int(rows[b]["Start_Timestamp"]), None
@@ -39,7 +43,7 @@ if len(begins) > 4:
         prev = e
     turn = []
     for i in begins[1:]:
-        if "k_solve_end" in rows[i - 1]["Kernel_Name"]:
+        if "k_solve_end" in rows[i - 1]["Kernel_Name"] and i in pool:
             turn.append(int(rows[i]["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"]))
     if turn:
         turn.sort()

@@ -141,17 +141,8 @@ __global__ __launch_bounds__(256) void k_gj_g(int step, int ndom, const GjStep *
 __device__ __forceinline__ const double *gj_src(const GjDom &dm, int kb) { return kb == 0 ? dm.T : dm.Z[kb & 1]; }
 // P = (pivot block)^{-1}: ONE wave per subdomain, lane r holds row r of the block in registers; a Gauss-Jordan step
 // broadcasts the scaled pivot row with v_readlane (no LDS round trips, no barriers in the 32-step dependency chain).
-__global__ __launch_bounds__(64) void k_gj_pivot(int step, int kb, int ndom, const GjStep *__restrict__ steps,
-                                                 const GjDom *__restrict__ doms) {
-  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
-  if (kb >= st.nb) return;
-  const GjDom dm = doms[blockIdx.z];
-  const int n = st.n0, k0 = kb * GJ_B, bs = min(GJ_B, n - k0);
-  const double *A = gj_src(dm, kb);
-  const int r = threadIdx.x & 31;                      // lanes 32..63 mirror lanes 0..31 (results of the lower half are stored)
-  double row[GJ_B];
-#pragma unroll
-  for (int c = 0; c < GJ_B; ++c) row[c] = (r < bs && c < bs) ? A[(k0 + r) + (size_t)(k0 + c) * n] : (r == c ? 1.0 : 0.0);
+// row[c] = lane r's row of a 32 x 32 SPD block (identity beyond the block's size) -> its inverse, in place
+__device__ __forceinline__ void gj_invert_rows(double (&row)[GJ_B], int r) {
 #pragma unroll
   for (int p = 0; p < GJ_B; ++p) {
     const double piv = 1.0 / lane_read(row[p], p);
@@ -167,9 +158,25 @@ __global__ __launch_bounds__(64) void k_gj_pivot(int step, int kb, int ndom, con
     }
     if (r != p) row[p] = -f * piv;
   }
+}
+// The pivot inverse of block step kb lives in P + (kb & 1) * 1024: the update launch of step kb reads it while one of its
+// workgroups writes the inverse for step kb + 1 into the other half (look-ahead, below). This kernel serves kb = 0 only.
+__global__ __launch_bounds__(64) void k_gj_pivot(int step, int kb, int ndom, const GjStep *__restrict__ steps,
+                                                 const GjDom *__restrict__ doms) {
+  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
+  if (kb >= st.nb) return;
+  const GjDom dm = doms[blockIdx.z];
+  const int n = st.n0, k0 = kb * GJ_B, bs = min(GJ_B, n - k0);
+  const double *A = gj_src(dm, kb);
+  const int r = threadIdx.x & 31;                      // lanes 32..63 mirror lanes 0..31 (results of the lower half are stored)
+  double row[GJ_B];
+#pragma unroll
+  for (int c = 0; c < GJ_B; ++c) row[c] = (r < bs && c < bs) ? A[(k0 + r) + (size_t)(k0 + c) * n] : (r == c ? 1.0 : 0.0);
+  gj_invert_rows(row, r);
+  double *Pd = dm.P + (kb & 1) * (GJ_B * GJ_B);
   if (threadIdx.x < GJ_B) {
 #pragma unroll
-    for (int c = 0; c < GJ_B; ++c) dm.P[r + c * GJ_B] = row[c];                  // column-major 32 x 32
+    for (int c = 0; c < GJ_B; ++c) Pd[r + c * GJ_B] = row[c];                    // column-major 32 x 32
   }
 }
 // one 64 x 64 tile of the updated matrix from the previous copy, on the fp64 matrix cores (v_mfma_f64_16x16x4_f64:
@@ -180,20 +187,33 @@ __global__ __launch_bounds__(64) void k_gj_pivot(int step, int kb, int ndom, con
 typedef double gj_d4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, const GjStep *__restrict__ steps,
                                                    const GjDom *__restrict__ doms) {
-  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
+  const int dz = blockIdx.z;   // (the subdomain as the FASTEST grid dimension, so that every look-ahead tile is dispatched in the first round, was measured: 55.8 us per launch against 51.7 — neighbouring workgroups then work on different matrices)
+  const GjStep st = steps[(size_t)step * ndom + dz];
   const int n = st.n0;
-  if (kb >= st.nb || (int)blockIdx.x * GJ_T >= n || (int)blockIdx.y * GJ_T >= n) return;
-  const GjDom dm = doms[blockIdx.z];
+  if (kb >= st.nb || (int)blockIdx.x * GJ_T >= n || (int)blockIdx.y * GJ_T >= n) return;   // (the swap below stays inside the grid: td * GJ_T < n)
+  const GjDom dm = doms[dz];
   const int k0 = kb * GJ_B, bs = min(GJ_B, n - k0);
   const double *A = gj_src(dm, kb);
   double *O = dm.Z[(kb + 1) & 1];
-  const int i0 = blockIdx.x * GJ_T, j0 = blockIdx.y * GJ_T;
+  // Look-ahead: the tile that holds the NEXT pivot block (diagonal tile td) also inverts it once it has updated it, so that
+  // the next block step needs no pivot launch of its own (16 us of a serial 32-step chain per step, 5 400 steps per
+  // realization at config 3). That tile is dealt first (swapped with tile (0, 0)) so that its longer life stays inside the launch.
+  const int k1 = k0 + GJ_B, td = k1 / GJ_T;
+  const bool ahead = kb + 1 < st.nb;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (ahead) {
+    if (bx == 0 && by == 0) bx = by = td;
+    else if (bx == td && by == td) bx = by = 0;
+  }
+  const bool special = ahead && bx == td && by == td;
+  const int i0 = bx * GJ_T, j0 = by * GJ_T;
   __shared__ double Pm[GJ_B][GJ_B + 1];          // P[r][c]
   __shared__ double R[GJ_B][GJ_T + 1];           // R = P * A[K, J]   (32 x 64)
   __shared__ double Cc[GJ_T][GJ_B + 1];          // A[I, K]           (64 x 32)
   __shared__ double Ak[GJ_B][GJ_T + 1];          // A[K, J]
   const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = l & 15, lk = l >> 4;
-  for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) Pm[e % GJ_B][e / GJ_B] = dm.P[e];
+  const double *Pcur = dm.P + (kb & 1) * (GJ_B * GJ_B);
+  for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) Pm[e % GJ_B][e / GJ_B] = Pcur[e];
   for (int e = threadIdx.x; e < GJ_B * GJ_T; e += 256) {
     const int t = e % GJ_B, c = e / GJ_B;        // A[k0 + t, j0 + c]: consecutive threads walk down a column
     Ak[t][c] = (t < bs && j0 + c < n) ? A[(k0 + t) + (size_t)(j0 + c) * n] : 0.0;
@@ -232,14 +252,15 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(R[kk + lk][16 * jt + lc], bneg, acc[jt], 0, 0, 0);
   }
-  if (i >= n) return;
   const bool ik = i >= k0 && i < k0 + bs;
+  const int bs1 = min(GJ_B, n - k1);
+  if (special) __syncthreads();                  // Ak is read for the last time above: it becomes the landing zone of the next pivot block
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int jl = 16 * jt + lk + 4 * v, j = j0 + jl;
-      if (j >= n) continue;
+      if (i >= n || j >= n) continue;
       const bool jk = j >= k0 && j < k0 + bs;
       double val = acc[jt][v];                                                 // A_ij - A_iK (P A_Kj)
       if (ik && jk) val = Pm[i - k0][j - k0];
@@ -250,7 +271,22 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
         val = -s2;
       }
       O[i + (size_t)j * n] = val;
+      if (special && i >= k1 && i < k1 + bs1 && j >= k1 && j < k1 + bs1) Ak[i - k1][j - k1] = val;   // (a trailing entry: K1 != K)
     }
+  if (!special) return;
+  __syncthreads();
+  if (threadIdx.x < 64) {                        // one wave: the same register-resident inversion as k_gj_pivot
+    const int r = threadIdx.x & 31;
+    double row[GJ_B];
+#pragma unroll
+    for (int c = 0; c < GJ_B; ++c) row[c] = (r < bs1 && c < bs1) ? Ak[r][c] : (r == c ? 1.0 : 0.0);
+    gj_invert_rows(row, r);
+    double *Pn = dm.P + ((kb + 1) & 1) * (GJ_B * GJ_B);
+    if (threadIdx.x < GJ_B) {
+#pragma unroll
+      for (int c = 0; c < GJ_B; ++c) Pn[r + c * GJ_B] = row[c];
+    }
+  }
 }
 // ---- the end of a subdomain's chain: S (upper triangle mirrored) = A_ΓΓ - B' Z_0 B; w = B' (Z_0 g_0)
 __global__ __launch_bounds__(256) void k_gj_final_pick(int ndom, const GjDom *__restrict__ doms, const int *__restrict__ c_ptr,
@@ -325,7 +361,7 @@ inline void gj_build(mi_setup_s &P) {
     const size_t nm = (size_t)std::max(1, D.max_lev), nt = (size_t)std::max<int>(std::max(1, D.max_lev), D.n_g);
     auto take = [&](size_t cnt) { const size_t o = tot; tot += (cnt + 31) / 32 * 32; return o; };
     off_T[d] = take(nt * nt); off_Z0[d] = take(nm * nm); off_Z1[d] = take(nm * nm);
-    off_y[d] = take(nm); off_g0[d] = take(nm); off_g1[d] = take(nm); off_P[d] = take(GJ_B * GJ_B);
+    off_y[d] = take(nm); off_g0[d] = take(nm); off_g1[d] = take(nm); off_P[d] = take(2 * GJ_B * GJ_B);
   }
   G->pool.alloc(tot + 32);
   MI_HIP(hipMemset(G->pool.p, 0, sizeof(double) * (tot + 32)));
@@ -379,7 +415,7 @@ inline void gj_enqueue(mi_setup_s &P, hipStream_t s, const double *ii, const dou
     hipLaunchKernelGGL(k_gj_scatter, dim3(8, 1, nd), dim3(256), 0, s, step, nd, st, dm, P.src.p, P.dst.p, ii);
     if (bI) hipLaunchKernelGGL(k_gj_g, dim3(cdiv(nm, 256), 1, nd), dim3(256), 0, s, step, nd, st, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ii, P.perm.p, bI);
     for (int kb = 0; kb < G.nb_step[step]; ++kb) {
-      hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nd), dim3(64), 0, s, step, kb, nd, st, dm);
+      if (kb == 0) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nd), dim3(64), 0, s, step, kb, nd, st, dm);   // later pivots: look-ahead in the update
       hipLaunchKernelGGL(k_gj_update, dim3(cdiv(nm, GJ_T), cdiv(nm, GJ_T), nd), dim3(256), 0, s, step, kb, nd, st, dm);
     }
   }
@@ -463,7 +499,7 @@ inline void pinv_blocks_fast(mi_ctx_s *c, int ndom, const int64_t *n_gamma_d, co
     const size_t n = (size_t)n_gamma_d[d], nn = std::max<size_t>(1, n * n);
     off[d] = run; run += n * n;
     auto take = [&](size_t cnt) { const size_t o = tot; tot += (cnt + 31) / 32 * 32; return o; };
-    oT[d] = take(nn); o0[d] = take(nn); o1[d] = take(nn); oP[d] = take(GJ_B * GJ_B);
+    oT[d] = take(nn); o0[d] = take(nn); o1[d] = take(nn); oP[d] = take(2 * GJ_B * GJ_B);
     nmax = std::max(nmax, n);
   }
   DevBuf<double> pool(tot + 32), norms((size_t)2 * ndom * 8);
@@ -478,7 +514,7 @@ inline void pinv_blocks_fast(mi_ctx_s *c, int ndom, const int64_t *n_gamma_d, co
   std_.upload(st, s); dmd.upload(dm, s);
   auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
   for (int kb = 0; kb < nbmax; ++kb) {
-    hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, ndom), dim3(64), 0, s, 0, kb, ndom, std_.p, dmd.p);
+    if (kb == 0) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, ndom), dim3(64), 0, s, 0, kb, ndom, std_.p, dmd.p);   // later pivots: look-ahead in the update
     hipLaunchKernelGGL(k_gj_update, dim3(cdiv((int)nmax, GJ_T), cdiv((int)nmax, GJ_T), ndom), dim3(256), 0, s, 0, kb, ndom, std_.p, dmd.p);
   }
   for (int d = 0; d < ndom; ++d) {

@@ -243,7 +243,7 @@ def setup_measurement(api, ctx, P, S, M):
     err = max(float((b.cpu().numpy() - np.asarray(P.Sd[d])).__abs__().max() / np.abs(P.Sd[d]).max()) for d, b in enumerate(setup.blocks(Sd)))
     return {"plan_once_s": round(t_plan, 3), "assemble_local_schurs_ms": round(t_S * 1e3, 1), "pinv_ms": round(t_pinv * 1e3, 1),
             "set_blocks_ms": round(t_set * 1e3, 2), "max_rel_diff_vs_host_blocks": err,
-            "note": "S_d: block Gauss-Jordan level elimination (fp64 MFMA), all subdomains batched, one hipGraph replay; pinv: rocSOLVER dsyevd per block"}
+            "note": "S_d: block Gauss-Jordan level elimination (fp64 MFMA), all subdomains batched, one hipGraph replay; look-ahead pivots; pinv: the same inversion for blocks whose norm certificate shows full rank, rocSOLVER dsyevd otherwise"}
 
 
 class StdoutToStderr:

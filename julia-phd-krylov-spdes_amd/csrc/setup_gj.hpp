@@ -208,9 +208,10 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   const bool special = ahead && bx == td && by == td;
   const int i0 = bx * GJ_T, j0 = by * GJ_T;
   __shared__ double Pm[GJ_B][GJ_B + 1];          // P[r][c]
-  __shared__ double R[GJ_B][GJ_T + 1];           // R = P * A[K, J]   (32 x 64)
+  // 42 KB of LDS: three workgroups per CU (with A[K, J] and R in buffers of their own, 58 KB, it was two)
+  __shared__ double R[GJ_B][GJ_T + 1];           // A[K, J] (32 x 64) first, then R = P * A[K, J], then (look-ahead tile) the next pivot block
   __shared__ double Cc[GJ_T][GJ_B + 1];          // A[I, K]           (64 x 32)
-  __shared__ double Ak[GJ_B][GJ_T + 1];          // A[K, J]
+  double (&Ak)[GJ_B][GJ_T + 1] = R;
   const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = l & 15, lk = l >> 4;
   const double *Pcur = dm.P + (kb & 1) * (GJ_B * GJ_B);
   for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) Pm[e % GJ_B][e / GJ_B] = Pcur[e];
@@ -233,15 +234,21 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   __syncthreads();
   {  // R = Pm * Ak: 2 x 4 blocks of 16 x 16, two per wave (t-block = wv & 1, j-blocks 2 (wv >> 1) and + 1)
     const int tb = wv & 1;
+    gj_d4 d[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int jbk = 2 * (wv >> 1) + q;
-      gj_d4 d = {0.0, 0.0, 0.0, 0.0};
+      d[q] = gj_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int kk = 0; kk < GJ_B; kk += 4)
-        d = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[16 * tb + lc][kk + lk], Ak[kk + lk][16 * jbk + lc], d, 0, 0, 0);
+        d[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[16 * tb + lc][kk + lk], Ak[kk + lk][16 * jbk + lc], d[q], 0, 0, 0);
+    }
+    __syncthreads();                             // every wave has read A[K, J]: the buffer becomes R
 #pragma unroll
-      for (int v = 0; v < 4; ++v) R[16 * tb + lk + 4 * v][16 * jbk + lc] = d[v];
+    for (int q = 0; q < 2; ++q) {
+      const int jbk = 2 * (wv >> 1) + q;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) R[16 * tb + lk + 4 * v][16 * jbk + lc] = d[q][v];
     }
   }
   __syncthreads();
@@ -254,7 +261,6 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   }
   const bool ik = i >= k0 && i < k0 + bs;
   const int bs1 = min(GJ_B, n - k1);
-  if (special) __syncthreads();                  // Ak is read for the last time above: it becomes the landing zone of the next pivot block
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
@@ -271,15 +277,23 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
         val = -s2;
       }
       O[i + (size_t)j * n] = val;
-      if (special && i >= k1 && i < k1 + bs1 && j >= k1 && j < k1 + bs1) Ak[i - k1][j - k1] = val;   // (a trailing entry: K1 != K)
+      acc[jt][v] = val;
     }
   if (!special) return;
+  __syncthreads();                               // R is read for the last time above: it becomes the landing zone of the next pivot block
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int j = j0 + 16 * jt + lk + 4 * v;
+      if (i >= k1 && i < k1 + bs1 && j >= k1 && j < k1 + bs1) R[i - k1][j - k1] = acc[jt][v];   // (trailing entries: K1 != K)
+    }
   __syncthreads();
   if (threadIdx.x < 64) {                        // one wave: the same register-resident inversion as k_gj_pivot
     const int r = threadIdx.x & 31;
     double row[GJ_B];
 #pragma unroll
-    for (int c = 0; c < GJ_B; ++c) row[c] = (r < bs1 && c < bs1) ? Ak[r][c] : (r == c ? 1.0 : 0.0);
+    for (int c = 0; c < GJ_B; ++c) row[c] = (r < bs1 && c < bs1) ? R[r][c] : (r == c ? 1.0 : 0.0);
     gj_invert_rows(row, r);
     double *Pn = dm.P + ((kb + 1) & 1) * (GJ_B * GJ_B);
     if (threadIdx.x < GJ_B) {

@@ -59,29 +59,63 @@ struct GjState {
 
 #pragma clang fp contract(fast)
 
-// T[i,j] = -(C' Z C)[i,j]  (0 at a subdomain's first step); the entries of A_kk are added by k_gj_scatter
+// T[i,j] = -(C' Z C)[i,j]  (0 at a subdomain's first step); the entries of A_kk are added by k_gj_scatter.
+// One thread per entry of the UPPER triangle (the mirror image is stored with it: C' Z C is symmetric, and the two
+// summation orders differ in the last bit only). A column of C holds a handful of entries (a P1 node has <= 3-4
+// neighbours in the adjacent level): up to PK of them are fetched into registers first, so that all picked entries of Z
+// are requested together instead of one dependent chain per entry; longer columns take the plain loops.
 __global__ __launch_bounds__(256) void k_gj_pick(int step, int ndom, const GjStep *__restrict__ steps, const GjDom *__restrict__ doms,
                                                  const int *__restrict__ c_ptr, const int *__restrict__ c_row,
                                                  const int *__restrict__ c_src, const double *__restrict__ ii_val) {
+  constexpr int PK = 4;
+  if (blockIdx.y < blockIdx.x) return;
   const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
   const int n0 = st.n0;
   const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
-  if (i >= n0 || j >= n0) return;
+  if (i >= n0 || j >= n0 || i > j) return;
   const GjDom dm = doms[blockIdx.z];
   double acc = 0.0;
   if (st.n1 > 0) {
     const double *Z = dm.Z[st.zin];
     const int *cp = c_ptr + st.cptr;
     const int ia = cp[i], ib = cp[i + 1], ja = cp[j], jb = cp[j + 1];
-    for (int p = ia; p < ib; ++p) {
-      const double ci = ii_val[c_src[p]];
-      const double *zr = Z + (size_t)c_row[p];            // Z[a, :] read as Z[a + b*n1] (symmetric)
-      double s = 0.0;
-      for (int q = ja; q < jb; ++q) s += zr[(size_t)c_row[q] * st.n1] * ii_val[c_src[q]];
-      acc += ci * s;
+    const int na = ib - ia, nb = jb - ja;
+    if (na <= PK && nb <= PK) {
+      int ra[PK], rb[PK], sa[PK], sb[PK];
+      double va[PK], vb[PK];
+#pragma unroll
+      for (int k = 0; k < PK; ++k) {
+        ra[k] = k < na ? c_row[ia + k] : 0; sa[k] = k < na ? c_src[ia + k] : 0;
+        rb[k] = k < nb ? c_row[ja + k] : 0; sb[k] = k < nb ? c_src[ja + k] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < PK; ++k) { va[k] = k < na ? ii_val[sa[k]] : 0.0; vb[k] = k < nb ? ii_val[sb[k]] : 0.0; }
+      double z[PK][PK];
+#pragma unroll
+      for (int p_ = 0; p_ < PK; ++p_)
+#pragma unroll
+        for (int q = 0; q < PK; ++q) z[p_][q] = (p_ < na && q < nb) ? Z[(size_t)ra[p_] + (size_t)rb[q] * st.n1] : 0.0;
+#pragma unroll
+      for (int p_ = 0; p_ < PK; ++p_)
+        if (p_ < na) {
+          double s = 0.0;
+#pragma unroll
+          for (int q = 0; q < PK; ++q)
+            if (q < nb) s += z[p_][q] * vb[q];
+          acc += va[p_] * s;
+        }
+    } else {
+      for (int p_ = ia; p_ < ib; ++p_) {
+        const double ci = ii_val[c_src[p_]];
+        const double *zr = Z + (size_t)c_row[p_];           // Z[a, :] read as Z[a + b*n1] (symmetric)
+        double s = 0.0;
+        for (int q = ja; q < jb; ++q) s += zr[(size_t)c_row[q] * st.n1] * ii_val[c_src[q]];
+        acc += ci * s;
+      }
     }
   }
   dm.T[i + (size_t)j * n0] = -acc;
+  if (i != j) dm.T[j + (size_t)i * n0] = -acc;
 }
 __global__ __launch_bounds__(256) void k_gj_scatter(int step, int ndom, const GjStep *__restrict__ steps, const GjDom *__restrict__ doms,
                                                     const int *__restrict__ src, const int *__restrict__ dst,

@@ -1779,6 +1779,17 @@ __device__ __forceinline__ double wave_lu_solve_reg(int nvec, const double *lu_s
   return b;
 }
 
+// W_loc[v * nloc + loc] = W[v * n + gidx[loc]]: the deflation vectors in the local order of the dense blocks, once per solve
+// (k_defl_mu then needs no Γ index before it can request its W entries: one memory round trip less per iteration)
+__global__ __launch_bounds__(NT) void k_gather_w_loc(int nvec, long long n_gamma, int nloc, const int *__restrict__ gidx,
+                                                     const double *__restrict__ W, double *__restrict__ W_loc) {
+  const int loc = blockIdx.x * NT + threadIdx.x;
+  if (loc >= nloc) return;
+  const long long g = gidx[loc];
+  const int v = blockIdx.y;
+  W_loc[(long long)v * nloc + loc] = W[(long long)v * n_gamma + g];
+}
+
 // Folded Def-PCG, between the ΠS and the S launch: mu = WtAW \ (WtA*z) from the per-tile partials (every workgroup
 // solves the same nvec x nvec system with the LU factors staged in LDS, nvec <= 64), then
 // wm_loc[loc] = (W*mu)[gidx[loc]] in column-axpy order (`W * mu`, defcg.jl:303) for this workgroup's slice of the
@@ -1787,7 +1798,7 @@ __global__ __launch_bounds__(1024) void k_defl_mu(const SolverState *st, int nve
                                                   const double *__restrict__ LU, const int *__restrict__ piv,
                                                   const double *__restrict__ W, long long n_gamma, int nloc,
                                                   const int *__restrict__ gidx, double *__restrict__ wm_loc,
-                                                  double *__restrict__ mu_out) {
+                                                  double *__restrict__ mu_out, const double *__restrict__ W_loc) {
   // One memory round trip for everything whose address is known at launch (stop flag, LU factors, pivots, Γ index, the
   // first batch of partials), a second one for the W entries behind the Γ index: the kernel is nothing but latency.
   __shared__ double lu_s[64 * 64];
@@ -1799,7 +1810,7 @@ __global__ __launch_bounds__(1024) void k_defl_mu(const SolverState *st, int nve
   for (int k = 0; k < 4; ++k) { const int i = (int)threadIdx.x + 1024 * k; lu_r[k] = i < nvec * nvec ? LU[i] : 0.0; }
   const int piv_r = (int)threadIdx.x < nvec ? piv[threadIdx.x] : 0;
   const int loc = blockIdx.x * 1024 + threadIdx.x;
-  const long long g = loc < nloc ? gidx[loc] : 0;
+  const long long g = (loc < nloc && !W_loc) ? gidx[loc] : 0;
   // rhs[v] = sum over tiles: TPV = 1024 / (nvec rounded up to a power of two) threads per vector, every thread's
   // partials requested in one batch, then a TPV-lane shuffle tree (fixed order: deterministic)
   int vpad = 1;
@@ -1809,12 +1820,14 @@ __global__ __launch_bounds__(1024) void k_defl_mu(const SolverState *st, int nve
   double a0[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) a0[k] = (v < nvec && l16 + tpv * k < ntiles) ? part_mu[(long long)v * ntiles + l16 + tpv * k] : 0.0;
-  asm volatile("" ::"s"(done0));
-  if (done0) return;
-  // W entries of this thread's local position: independent of mu, in flight during the sums and the solve
+  // W entries of this thread's local position: independent of mu, in flight during the sums and the solve (from the
+  // pre-gathered W_loc they need no Γ index: requested with everything else, ahead of the exit test)
   double w0[20];                                        // the first 20 columns of W at g
 #pragma unroll
-  for (int u = 0; u < 20; ++u) w0[u] = (u < nvec && loc < nloc) ? W[(long long)u * n_gamma + g] : 0.0;
+  for (int u = 0; u < 20; ++u)
+    w0[u] = (u < nvec && loc < nloc) ? (W_loc ? W_loc[(long long)u * nloc + loc] : W[(long long)u * n_gamma + g]) : 0.0;
+  asm volatile("" ::"s"(done0));
+  if (done0) return;
 #pragma unroll
   for (int k = 0; k < 4; ++k) { const int i = (int)threadIdx.x + 1024 * k; if (i < nvec * nvec) lu_s[i] = lu_r[k]; }
   if ((int)threadIdx.x < nvec) piv_s[threadIdx.x] = piv_r;
@@ -1856,7 +1869,8 @@ __global__ __launch_bounds__(1024) void k_defl_mu(const SolverState *st, int nve
     for (int q0 = 20; q0 < nvec; q0 += 16) {      // beyond the preloaded columns: sixteen in flight per thread
       double w[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) w[u] = q0 + u < nvec ? W[(long long)(q0 + u) * n_gamma + g] : 0.0;
+      for (int u = 0; u < 16; ++u)
+        w[u] = q0 + u < nvec ? (W_loc ? W_loc[(long long)(q0 + u) * nloc + loc] : W[(long long)(q0 + u) * n_gamma + g]) : 0.0;
 #pragma unroll
       for (int u = 0; u < 16; ++u)
         if (q0 + u < nvec) wm += w[u] * mu_s[q0 + u];

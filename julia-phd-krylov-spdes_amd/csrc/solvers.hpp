@@ -133,6 +133,7 @@ struct SolverWorkspace {
   // deflation
   DevBuf<double> W, AW, LU, mu, part_mu, gram;
   DevBuf<double> fold_mu, fold_wm;  // folded Def-PCG: per-tile partials of WtA*z, (W*mu) in local order
+  DevBuf<double> fold_wloc;         //                  W in the local order of the blocks (nvec x nloc), gathered per solve
   DevBuf<long long> fold_dbg;       // MI355_FOLD_DEBUG=1: 64 launches x 8 stamps of one workgroup of the folded launches
   DevBuf<double> cf_pz, cf_rr, cf_rz;  // 2-launch sparse pcg: two buffers of interleaved (p, z) pairs, per-block partials
   DevBuf<int> piv;
@@ -392,7 +393,7 @@ struct Krylov {
       Md->gemv_pcg(1, fold_args(1));
       if (nvec > 0) {  // mu = WtAW \ (WtA * z); W*mu in local order for the S launch (defcg.jl:301-303)
         hipLaunchKernelGGL(k_defl_mu, dim3((Ad->maps.nloc + 1023) / 1024), dim3(1024), 0, s, ws.st, nvec, Md->ntiles, ws.fold_mu.p,
-                           ws.LU.p, ws.piv.p, ws.W.p, (long long)n, Ad->maps.nloc, Ad->maps.gidx.p, ws.fold_wm.p, ws.mu.p);
+                           ws.LU.p, ws.piv.p, ws.W.p, (long long)n, Ad->maps.nloc, Ad->maps.gidx.p, ws.fold_wm.p, ws.mu.p, ws.fold_wloc.p);
         MI_HIP(hipGetLastError());
       }
       Ad->gemv_pcg(0, fold_args(0));
@@ -626,6 +627,11 @@ struct Krylov {
     MI_HIP(hipGetLastError());
     if (nvec > 0) {
       MI_HIP(hipMemcpyAsync(ws.W.p, W_in, vb * nvec, hipMemcpyDeviceToDevice, s));
+      if (fold) {
+        hipLaunchKernelGGL(k_gather_w_loc, dim3((Ad->maps.nloc + NT - 1) / NT, nvec), dim3(NT), 0, s, nvec, (long long)n, Ad->maps.nloc,
+                           Ad->maps.gidx.p, ws.W.p, ws.fold_wloc.p);
+        MI_HIP(hipGetLastError());
+      }
       A->apply_multi(ws.W.p, n, nvec, ws.AW.p, n);                           // WtA[v,:] = A*W[:,v]
       hipLaunchKernelGGL(k_small_gram, dim3(nvec, nvec), dim3(NT), 0, s, n, ws.AW.p, ws.W.p, ws.gram.p, nvec);  // WtAW
       MI_HIP(hipGetLastError());
@@ -649,9 +655,10 @@ struct Krylov {
     if (nvec > 0) ws.ensure_deflation(nvec);
     if (nvec > 0 && fold) {
       const size_t need_mu = (size_t)nvec * Md->ntiles + 1, need_wm = (size_t)Ad->maps.nloc + 1;
-      if (ws.fold_mu.n < need_mu || ws.fold_wm.n < need_wm) {
+      const size_t need_wl = (size_t)nvec * Ad->maps.nloc + 1;
+      if (ws.fold_mu.n < need_mu || ws.fold_wm.n < need_wm || ws.fold_wloc.n < need_wl) {
         ws.drop_graphs();  // buffers move
-        ws.fold_mu.alloc(need_mu); ws.fold_wm.alloc(need_wm);
+        ws.fold_mu.alloc(need_mu); ws.fold_wm.alloc(need_wm); ws.fold_wloc.alloc(need_wl);
       }
     }
     if (csrfold()) {

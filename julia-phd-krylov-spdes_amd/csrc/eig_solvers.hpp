@@ -159,13 +159,19 @@ struct EigKrylov {
     Snapshot h = fetch();
 
     const bool use_graph = k.ctx->chunk > 0 && k.A->graph_safe() && (!k.M || k.M->graph_safe()) && !k.ctx->no_graph && !k.ctx->has_comm();
+    // A replay runs to the next thick restart; launches behind the stop rule return at once but still cost a launch each
+    // (~4.5 us x 7-10 kernels per iteration). When the previous solve with these operators took `predicted` iterations, the
+    // replay that would overshoot it is cut there (one more replay follows if this solve needs more).
+    const GraphKey pk{k.A, k.M, nvec, -1000 - (int)kind};
+    const int predicted = ws.predicted.count(pk) ? ws.predicted[pk] : 0;
     for (int64_t guard = 0; guard < maxit + 4; ++guard) {
       if (h.es.restart_pending) {
         restart(h);
         h.es = fetch().es;
       }
       if (h.st.done) break;
-      const int seg = spdim - h.es.ivec;  // iterations up to and including the one that fills the window
+      int seg = spdim - h.es.ivec;  // iterations up to and including the one that fills the window
+      if (predicted > 0 && h.st.it < predicted && h.st.it + seg > predicted) seg = (int)(predicted - h.st.it);
       if (use_graph) {
         if (ws.graphs.size() > 48) ws.drop_graphs();
         MI_HIP(hipGraphLaunch(k.graph(seg), s));
@@ -175,6 +181,7 @@ struct EigKrylov {
       h = fetch();
     }
     if (!h.st.done) raise(MI_ERR_HIP, "internal: eig Krylov loop ended without the stop flag (it=%lld)", h.st.it);
+    ws.predicted[pk] = (int)std::max<long long>(1, h.st.it);
     const int rc_extract = final_extraction(h);
 
     const size_t vb = sizeof(double) * (size_t)n;

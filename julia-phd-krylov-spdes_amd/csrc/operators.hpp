@@ -566,7 +566,7 @@ struct InteriorCg {
   IcgMeta meta{};
   long long total_iterations = 0;  // statistics: iterations of the slowest subdomain, summed over solves
   // 2-launch form (k_icg_spmv / k_icg_update_blk), MI355_ICG_FUSED=1: measured SLOWER than the 3-launch loop at 1 M DoF
-  // (62.7 vs 45.6 us per iteration: the on-the-fly direction doubles the gathered bytes of a 7 M-non-zero SpMV), so
+  // (51.6 vs 37.6 us per iteration: the on-the-fly direction doubles the gathered bytes of a 7 M-non-zero SpMV), so
   // it is an opt-in kept for its tests; DESIGN.md §5
   bool folded = false;
   IcgFold fm{};
@@ -574,6 +574,7 @@ struct InteriorCg {
   DevBuf<IcgDomState> dst;   // cur[ndl], nxt[ndl]
   DevBuf<double> ur, part_rz, dinv, rho;
   DevBuf<IcgBlkInfo> binfo;
+  DevBuf<int> dom_p0, dom_p1;
   IcgDomState *dst_host = nullptr;
   std::vector<int> ioff_h;
   int npieces_grid = 0;
@@ -602,7 +603,7 @@ struct InteriorCg {
     chunk = std::max(1, env_int("MI355_ICG_CHUNK", 64));
     rho.alloc(2 * (size_t)ndl + 2); part_rz.alloc((size_t)A.nblocks + 1);
     meta = IcgMeta{A.blk.p, blk_dom.p, dom_b0.p, dom_b1.p, res_cur.p, res_nxt.p, tol.p, done_cur.p, done_nxt.p, iters.p, 0,
-                   nullptr, rho.p, rho.p + ndl + 1, part_rz.p};
+                   nullptr, rho.p, rho.p + ndl + 1, part_rz.p, nullptr, nullptr};
     {  // 1 / diagonal of A_II (for the optional Jacobi `Pl`)
       std::vector<double> dg((size_t)n + 1, 1.0);
       for (int r_ = 0; r_ < a.n_rows; ++r_)
@@ -612,7 +613,8 @@ struct InteriorCg {
     }
     folded = env_int("MI355_ICG_FUSED", 0) != 0;
     ioff_h = ioff;
-    if (folded) build_fold(a, b0, b1);
+    build_fold(a, b0, b1);   // the pieces serve both forms
+    meta.p_rz = part_rz.p; meta.dom_p0 = dom_p0.p; meta.dom_p1 = dom_p1.p;
   }
   // Pieces of the vector kernel: rows cut at subdomain boundaries and at the XCD boundaries of the SpMV's block dealing,
   // then into runs of <= `rows_per` rows; workgroup k works on XCD k & 7, so the pieces are interleaved per XCD.
@@ -636,21 +638,24 @@ struct InteriorCg {
         const int cnt = (hi - lo + rows_per - 1) / rows_per;
         for (int k = 0; k < cnt; ++k) {
           const int a0 = lo + (int)((long long)(hi - lo) * k / cnt), a1 = lo + (int)((long long)(hi - lo) * (k + 1) / cnt);
-          per_xcd[x].push_back(IcgPiece{a0, a1, d, slot, b0[d], b1[d], slot == p0[d] ? 1 : 0, 0});
+          per_xcd[x].push_back(IcgPiece{a0, a1, d, slot, b0[d], b1[d], slot == p0[d] ? 1 : 0, 0, p0[d], 0});
           ++slot;
         }
       }
       p1[d] = slot;
       if (p1[d] - p0[d] > NT) ok = false;   // k_icg_spmv sums a subdomain's partials with one load per thread
     }
-    if (!ok) { folded = false; return; }
+    if (!ok) folded = false;   // (the 2-launch form sums a subdomain's partials with one load per thread)
+    for (auto &v : per_xcd)
+      for (auto &pc : v) pc.p1 = p1[pc.dom];
     size_t mx = 0;
     for (auto &v : per_xcd) mx = std::max(mx, v.size());
-    std::vector<IcgPiece> tab(8 * std::max<size_t>(1, mx), IcgPiece{0, 0, 0, 0, 0, 0, 0, 0});
+    std::vector<IcgPiece> tab(8 * std::max<size_t>(1, mx), IcgPiece{0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
     for (int x = 0; x < 8; ++x)
       for (size_t j = 0; j < per_xcd[x].size(); ++j) tab[j * 8 + x] = per_xcd[x][j];
     npieces_grid = (int)tab.size();
     pieces.upload(tab, s);
+    dom_p0.upload(p0, s); dom_p1.upload(p1, s);
     {
       std::vector<int> bdh(A.nblocks), nih(ndl);
       MI_HIP(hipStreamSynchronize(s));
@@ -666,7 +671,7 @@ struct InteriorCg {
     std::vector<IcgDomState> st0(2 * (size_t)ndl);
     for (auto &q : st0) { q.rho_prev = 1.0; q.tol = 0.0; q.res = 0.0; q.it = 0; q.done = 1; }   // an empty interior stays "done"
     dst.upload(st0, s);
-    ur.alloc(4 * (size_t)n + 4);
+    if (folded) ur.alloc(4 * (size_t)n + 4);
     if (part_rz.n < (size_t)slot + 1) part_rz.alloc((size_t)slot + 1);
     if (p_rr.n < (size_t)slot + 1) p_rr.alloc((size_t)slot + 1);
     MI_HIP(hipHostMalloc((void **)&dst_host, sizeof(IcgDomState) * (ndl + 1)));
@@ -700,8 +705,8 @@ struct InteriorCg {
       return;
     }
     A.launch(0, u.p, nullptr, c.p, nullptr, s, u.p, p_uc.p);  // c = A u, partial u'c
-    hipLaunchKernelGGL(k_icg_update, dim3(A.nblocks), dim3(NT), 0, s, meta, p_uc.p, u.p, c.p, x, r.p, p_rr.p);
-    hipLaunchKernelGGL(k_icg_direction, dim3(A.nblocks), dim3(NT), 0, s, meta, p_rr.p, r.p, u.p, n_i.p);
+    hipLaunchKernelGGL(k_icg_update, dim3(npieces_grid), dim3(NT), 0, s, meta, pieces.p, p_uc.p, u.p, c.p, x, r.p, p_rr.p);
+    hipLaunchKernelGGL(k_icg_direction, dim3(npieces_grid), dim3(NT), 0, s, meta, pieces.p, p_rr.p, r.p, u.p, n_i.p);
     MI_HIP(hipGetLastError());
   }
   // x = A_II^{-1} rhs for every local subdomain (device pointers), to the relative tolerance
@@ -711,7 +716,7 @@ struct InteriorCg {
     if (folded) {
       hipLaunchKernelGGL(k_icg_fold_init, dim3(npieces_grid), dim3(NT), 0, s, fm, pieces.p, rhs, x);
     } else {
-      hipLaunchKernelGGL(k_icg_init, dim3(A.nblocks), dim3(NT), 0, s, meta, rhs, x, r.p, u.p, p_rr.p);
+      hipLaunchKernelGGL(k_icg_init, dim3(npieces_grid), dim3(NT), 0, s, meta, pieces.p, rhs, x, r.p, u.p, p_rr.p);
       hipLaunchKernelGGL(k_icg_start, dim3(ndl), dim3(NT), 0, s, meta, p_rr.p, reltol);
     }
     MI_HIP(hipGetLastError());

@@ -59,6 +59,11 @@ struct GjState {
 
 #pragma clang fp contract(fast)
 
+// (a runtime index into an array member of a by-value struct sends the whole struct to scratch memory: 120 bytes per thread
+// in every kernel below; a select keeps it in scalar registers)
+#define GJ_Z(dm, k) ((k) ? (dm).Z[1] : (dm).Z[0])
+#define GJ_G(dm, k) ((k) ? (dm).g[1] : (dm).g[0])
+
 // T[i,j] = -(C' Z C)[i,j]  (0 at a subdomain's first step); the entries of A_kk are added by k_gj_scatter.
 // One thread per entry of the UPPER triangle (the mirror image is stored with it: C' Z C is symmetric, and the two
 // summation orders differ in the last bit only). A column of C holds a handful of entries (a P1 node has <= 3-4
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256) void k_gj_pick(int step, int ndom, const GjSte
   const GjDom dm = doms[blockIdx.z];
   double acc = 0.0;
   if (st.n1 > 0) {
-    const double *Z = dm.Z[st.zin];
+    const double *Z = GJ_Z(dm, st.zin);
     const int *cp = c_ptr + st.cptr;
     const int ia = cp[i], ib = cp[i + 1], ja = cp[j], jb = cp[j + 1];
     const int na = ib - ia, nb = jb - ja;
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void k_gj_zg(int step, int ndom, const GjStep 
   const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
   if (st.n0 == 0 || (int)blockIdx.x * 64 >= st.n1) return;
   const GjDom dm = doms[blockIdx.z];
-  gj_gemv64(dm.Z[st.zin], st.n1, dm.g[(step + 1) & 1], dm.y);
+  gj_gemv64(GJ_Z(dm, st.zin), st.n1, GJ_G(dm, (step + 1) & 1), dm.y);
 }
 // g_k = b_k - C_k' y
 __global__ __launch_bounds__(256) void k_gj_g(int step, int ndom, const GjStep *__restrict__ steps, const GjDom *__restrict__ doms,
@@ -168,11 +173,11 @@ __global__ __launch_bounds__(256) void k_gj_g(int step, int ndom, const GjStep *
     for (int p = cp[j]; p < cp[j + 1]; ++p) s += ii_val[c_src[p]] * dm.y[c_row[p]];
     v -= s;
   }
-  dm.g[step & 1][j] = v;
+  GJ_G(dm, step & 1)[j] = v;
 }
 
 // ---- block Gauss-Jordan inversion of T (n0 x n0, SPD), block step kb: source = T (kb == 0) or Z[kb & 1], destination Z[(kb + 1) & 1]
-__device__ __forceinline__ const double *gj_src(const GjDom &dm, int kb) { return kb == 0 ? dm.T : dm.Z[kb & 1]; }
+__device__ __forceinline__ const double *gj_src(const GjDom &dm, int kb) { return kb == 0 ? dm.T : GJ_Z(dm, kb & 1); }
 // P = (pivot block)^{-1}: ONE wave per subdomain, lane r holds row r of the block in registers; a Gauss-Jordan step
 // broadcasts the scaled pivot row with v_readlane (no LDS round trips, no barriers in the 32-step dependency chain).
 // row[c] = lane r's row of a 32 x 32 SPD block (identity beyond the block's size) -> its inverse, in place
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   const GjDom dm = doms[dz];
   const int k0 = kb * GJ_B, bs = min(GJ_B, n - k0);
   const double *A = gj_src(dm, kb);
-  double *O = dm.Z[(kb + 1) & 1];
+  double *O = GJ_Z(dm, (kb + 1) & 1);
   // Look-ahead: the tile that holds the NEXT pivot block (diagonal tile td) also inverts it once it has updated it, so that
   // the next block step needs no pivot launch of its own (16 us of a serial 32-step chain per step, 5 400 steps per
   // realization at config 3). That tile is dealt first (swapped with tile (0, 0)) so that its longer life stays inside the launch.
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(256) void k_gj_final_pick(int ndom, const GjDom *__
   if (i >= ng || j >= ng) return;
   double acc = 0.0;
   if (dm.n_last > 0) {
-    const double *Z = dm.Z[dm.zfin];
+    const double *Z = GJ_Z(dm, dm.zfin);
     const int *cp = c_ptr + dm.bptr;
     for (int p = cp[i]; p < cp[i + 1]; ++p) {
       const double ci = ig_val[c_src[p]];
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256) void k_gj_final_sym(int ndom, const GjDom *__r
 __global__ __launch_bounds__(256) void k_gj_final_zg(int ndom, int last_step, const GjDom *__restrict__ doms) {
   const GjDom dm = doms[blockIdx.z];
   if ((int)blockIdx.x * 64 >= dm.n_last) return;
-  gj_gemv64(dm.Z[dm.zfin], dm.n_last, dm.g[last_step & 1], dm.y);
+  gj_gemv64(GJ_Z(dm, dm.zfin), dm.n_last, GJ_G(dm, last_step & 1), dm.y);
 }
 __global__ __launch_bounds__(256) void k_gj_final_w(int ndom, const GjDom *__restrict__ doms, const int *__restrict__ c_ptr,
                                                     const int *__restrict__ c_row, const int *__restrict__ c_src,

@@ -343,6 +343,12 @@ def main():
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_dist
     if multi:
+        if "RANK" not in os.environ:      # --force-dist from a plain `python bench.py`: a one-rank rendezvous on the loopback
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = graft.load_package()

@@ -9,8 +9,9 @@
 // where C_k = A_{k+1,k} and B = A_IΓ[L_0, :] are SPARSE (a P1 node has <= 3-4 neighbours in the adjacent level), so every
 // entry of C' Z C is a sum of a dozen picked entries of Z ("pick" kernels, one thread per entry) and the only dense
 // O(n^3) work per level is the inversion of the SPD matrix T_k: an in-place-style block Gauss-Jordan inversion without
-// pivoting (block size 32; the k-th pivot block of an SPD matrix is its k-th Schur complement, SPD again), 2 launches
-// per block step: the 32 x 32 pivot block is inverted by one workgroup in LDS, then one launch updates the whole
+// pivoting (block size 32; the k-th pivot block of an SPD matrix is its k-th Schur complement, SPD again): the 32 x 32
+// pivot block is inverted by one wave (rows in registers) — for the first block of a level in a launch of its own, for the
+// others inside the previous step's update launch (look-ahead) —, and one launch per block step updates the whole
 // matrix from the previous copy (ping-pong buffers: no launch reads what it writes) —
 //     row panel   P A_Kj,   column panel   -A_iK P,   trailing   A_ij - A_iK (P A_Kj),   pivot block   P.
 // All subdomains advance together (grid.z), aligned so that they reach level 0 in the same step. The launch sequence

@@ -320,6 +320,34 @@ i64 orc_interior_cg(i64 n, const i64 *colptr, const i64 *rowval, const double *n
   return it;
 }
 
+/* -- assemble_local_schurs, one subdomain (EPDD.jl:667-695). The reference materialises the LinearMap
+ *    xd -> apply_local_schur(A_IIdd, A_IΓdd, A_ΓΓdd, xd; reltol) (EPDD.jl:639-654) with `Array(Sd_map)` — LinearMaps
+ *    fills column j with the map applied to the j-th unit vector — and keeps `Symmetric(...)`, i.e. the UPPER triangle
+ *    mirrored (entry (i,j), i <= j, of column j), then `sparse(...)`. Quirk kept (:676-691): the `isnothing(preconds)`
+ *    test is inverted, so a caller that passes preconditioners gets the plain CG below and one that passes none gets a
+ *    MethodError; the interior solve is therefore always the unpreconditioned `IterativeSolvers.cg(...; reltol)`.
+ *    S is n_d x n_d column-major. Returns the total number of interior CG iterations. */
+i64 orc_assemble_local_schur(i64 n_i, i64 n_d, const i64 *ii_ptr, const i64 *ii_idx, const double *ii_val,
+                             const i64 *ig_ptr, const i64 *ig_idx, const double *ig_val,
+                             const i64 *gg_ptr, const i64 *gg_idx, const double *gg_val, double reltol, double *S) {
+  double *xd = (double *)calloc((size_t)(3 * n_d + 2 * n_i + 5), sizeof(double));
+  double *yd = xd + n_d, *td = yd + n_d, *rhs = td + n_d, *sol = rhs + n_i;
+  i64 its = 0;
+  for (i64 j = 0; j < n_d; ++j) {
+    for (i64 l = 0; l < n_d; ++l) xd[l] = 0.0;
+    xd[j] = 1.0;
+    orc_csc_spmv(n_d, n_d, gg_ptr, gg_idx, gg_val, xd, yd);        /* Sdxd = A_ΓΓdd * xd            (:645) */
+    orc_csc_spmv(n_i, n_d, ig_ptr, ig_idx, ig_val, xd, rhs);        /* A_IΓdd * xd                   (:647) */
+    its += orc_interior_cg(n_i, ii_ptr, ii_idx, ii_val, rhs, sol, reltol);
+    orc_csc_spmv_t(n_i, n_d, ig_ptr, ig_idx, ig_val, sol, td);      /* A_IΓdd' * v                   (:652) */
+    for (i64 l = 0; l < n_d; ++l) S[l + j * n_d] = yd[l] - td[l];   /* Sdxd .-= ...                         */
+  }
+  for (i64 j = 0; j < n_d; ++j)                                     /* Symmetric(M): upper triangle rules   */
+    for (i64 i = j + 1; i < n_d; ++i) S[i + j * n_d] = S[j + i * n_d];
+  free(xd);
+  return its;
+}
+
 /* ------------------------------------------------------------------ dense `A \ b` (LU, partial pivoting) */
 /* LAPACK dgetf2/dgetrs semantics on a column-major n x n copy. Returns 0, or k+1 if U[k,k]==0
  * (Julia throws SingularException(k+1)). */

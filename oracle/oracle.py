@@ -263,6 +263,42 @@ def interior_cg_solvers(A_IIdd, reltol: float = 1e-9):
     return [lambda rhs, A=A: interior_cg(A, rhs, reltol)[0] for A in A_IIdd]
 
 
+def assemble_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd, reltol: float = 1e-9, return_iterations: bool = False):
+    """`assemble_local_schurs(A_IIdd, A_IΓdd, A_ΓΓdd; preconds, reltol=1e-9)` (EPDD.jl:667-695) in the reference's own
+    semantics: column j of S_d is `apply_local_schur` (EPDD.jl:639-654) of the j-th unit vector, its interior solve the
+    UNPRECONDITIONED `IterativeSolvers.cg(A_IIdd, ·, reltol=reltol)` from a zero guess (the inverted `isnothing` test
+    of :676 means passed preconditioners are ignored), then `Symmetric(·)` (upper triangle mirrored). Returns dense
+    column-major blocks (the reference wraps them in `sparse`, which stores every entry)."""
+    L = lib()
+    out, its = [], []
+    for A_II, A_IG, A_GG in zip(A_IIdd, A_IΓdd, A_ΓΓdd):
+        ii, ig, gg = (sp.csc_matrix(M) for M in (A_II, A_IG, A_GG))
+        for M in (ii, ig, gg):
+            M.sort_indices()
+        n_i, n_d = ig.shape
+        S = np.zeros((n_d, n_d), order="F")
+        arrs = []
+        for M in (ii, ig, gg):
+            arrs += [_i64(M.indptr), _i64(M.indices), _f64(M.data)]
+        fn = L.orc_assemble_local_schur
+        fn.restype = C.c_int64
+        it = fn(C.c_int64(n_i), C.c_int64(n_d), _p(arrs[0], i64p), _p(arrs[1], i64p), _p(arrs[2], f64p),
+                _p(arrs[3], i64p), _p(arrs[4], i64p), _p(arrs[5], f64p), _p(arrs[6], i64p), _p(arrs[7], i64p),
+                _p(arrs[8], f64p), C.c_double(reltol), _p(S, f64p))
+        out.append(S)
+        its.append(int(it))
+    return (out, its) if return_iterations else out
+
+
+def prepare_neumann_neumann_schur_precond(Sd):
+    """`prepare_neumann_neumann_schur_precond(Sd_local_mat, ind_Γd_Γ2l, node_Γ_cnt)` (EPDD.jl:1201-1220):
+    `ΠSd[idom] = LinearAlgebra.pinv(Array(Sd[idom]), rtol = sqrt(eps(Float64)))`. Julia's `pinv(A; rtol)` is the
+    SVD `A = U Σ V'` with every σ_i <= rtol·σ_max dropped — numpy's `pinv(rcond)` is the same definition on the same
+    LAPACK `gesdd` factorisation (third-party arithmetic: Julia 1.5 stdlib LinearAlgebra, not under /root/reference)."""
+    rtol = float(np.sqrt(np.finfo(np.float64).eps))
+    return [np.asfortranarray(np.linalg.pinv(np.asarray(S, dtype=np.float64), rcond=rtol)) for S in Sd]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # eigCG family and Init-CG (SURVEY.md §8 row f1): numpy restatement, one reference statement per line.
 # Dense small-matrix calls follow Julia's LinearAlgebra semantics:

@@ -80,14 +80,46 @@ int mi_ctx_set_chunk(mi_ctx_t ctx, int iterations_per_graph);
 int mi_comm_unique_id(void *id_out);
 int mi_ctx_comm_init(mi_ctx_t ctx, const void *id, int rank, int n_ranks);
 int mi_ctx_comm_destroy(mi_ctx_t ctx);
-/* Test facility: an in-process stand-in for the communicator. `n_ranks` contexts of ONE process (one host thread each,
- * any devices, typically the same one) call mi_ctx_loopback_init with the same group and then behave like ranks of a
- * multi-GPU job: operators built from a slice of the subdomains are sharded and their all-reduces sum the ranks'
- * buffers through device memory with host-side rendezvous (eager launches, no graphs). RCCL refuses two ranks on
- * one device; this is how the sharded paths are exercised on a single-GPU box (tests/test_gpu_parity.py). */
+/* The one-shot PEER EXCHANGE (the same `(+)` over subdomains, EllipticPdePllDomainDecomposition.jl:10-14, without a
+ * collective library in the loop): every rank owns an arena of peer-visible device memory; after a sharded launch a rank
+ * WRITES its entries of the contribution table into every rank's arena (xGMI peer stores), releases them, stores its
+ * exchange number into one flag per arena and continues when its own flags have all arrived (bounded wait: an expired
+ * wait makes the solve return MI_ERR_COMM, never hang). No arithmetic on the way: the tables of the ranks are disjoint,
+ * so the bits are the single-GPU loop's. Everything is kernels on the context's stream — captured into the iteration
+ * graphs. Call order, on every rank: mi_ctx_peer_init; mi_ctx_peer_export and ship the MI_PEER_HANDLE_BYTES to the other
+ * ranks by any means (torch.distributed / MPI / Julia Distributed); mi_ctx_peer_import for every other rank (ranks that
+ * are contexts of the SAME process pass the exporter's `base` instead of a handle); mi_ctx_peer_ready. With RCCL also
+ * attached the peer exchange carries the tables of the folded PCG launches and RCCL the generic all-reduces; alone it
+ * carries both. mi_ctx_set_exchange(ctx, 0) switches it off again (RCCL for everything), 1 on. Sharded operators must be
+ * created in the same order with the same sizes on every rank (their tables sit at equal offsets of every arena). */
+#define MI_PEER_HANDLE_BYTES 64
+int mi_ctx_peer_init(mi_ctx_t ctx, int rank, int n_ranks, int64_t arena_bytes /* 0: 64 MiB */);
+int mi_ctx_peer_export(mi_ctx_t ctx, void *handle_out /* MI_PEER_HANDLE_BYTES */, void **base_out);
+int mi_ctx_peer_import(mi_ctx_t ctx, int rank, const void *handle, void *same_process_base);
+int mi_ctx_peer_ready(mi_ctx_t ctx);
+int mi_ctx_set_exchange(mi_ctx_t ctx, int use_peer_exchange);
+/* Introspection for tests and benchmarks: which path ran. NO_GRAPH: 1 when this context launches eagerly (a collective
+ * that cannot be captured); PEER_EXCHANGE: 0 off, 1 on, 2 on with a fine-grained arena; GRAPH_REPLAYS: hipGraphLaunch
+ * calls of the solvers so far; EXCHANGES: exchanges this rank has signalled (synchronises the stream). */
+#define MI_QUERY_NO_GRAPH 0
+#define MI_QUERY_PEER_EXCHANGE 1
+#define MI_QUERY_GRAPH_REPLAYS 2
+#define MI_QUERY_EXCHANGES 3
+int mi_ctx_query(mi_ctx_t ctx, int what, int64_t *out);
+/* Test facility: in-process ranks. `n_ranks` contexts of ONE process (one host thread each, typically all on the same
+ * device) call mi_ctx_loopback_init with the same group and then behave like ranks of a multi-GPU job: operators built
+ * from a slice of the subdomains are sharded. RCCL refuses two ranks on one device; this is how the sharded paths are
+ * exercised on a single-GPU box (tests/test_gpu_multirank.py, tests/test_gpu_parity.py). The group joins its contexts by
+ * the peer exchange above (same-process arenas): device-side flags, graph-captured like the production path. Kernels of
+ * one rank then wait for kernels of another, which needs one hardware queue per rank and copies that do not queue up
+ * behind each other: set GPU_MAX_HW_QUEUES >= n_ranks and GPU_FORCE_BLIT_COPY_SIZE=1048576 in the environment BEFORE the
+ * first HIP call (the runtime's defaults are 4 queues and 16 KiB). mi_ctx_loopback_init runs trial exchanges with a short
+ * bound; if one expires (or GPU_MAX_HW_QUEUES < n_ranks) the whole group falls back to host-side rendezvous with eager
+ * launches, as does mode 1. mode: 0 automatic, 1 host rendezvous. One process per GPU needs neither setting. */
 int mi_loopback_group_create(int n_ranks, void **group);
 int mi_loopback_group_destroy(void *group);
 int mi_ctx_loopback_init(mi_ctx_t ctx, void *group, int rank);
+int mi_loopback_group_set_mode(void *group, int mode);
 int mi_ctx_allreduce_sum(mi_ctx_t ctx, double *buf, int64_t n); /* in place, follows pointer mode */
 
 /* ---------------------------------------------------------------- operators

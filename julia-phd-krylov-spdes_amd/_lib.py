@@ -18,6 +18,7 @@ MI_ERR_BAD_ARG, MI_ERR_HIP, MI_ERR_SINGULAR, MI_ERR_RES_CAPACITY = -1, -2, -3, -
 MI_ERR_COMM, MI_ERR_NO_DEVICE, MI_ERR_CALLBACK, MI_ERR_BOUNDS = -5, -6, -7, -8
 MI_PTR_HOST, MI_PTR_DEVICE = 0, 1
 MI_COMM_ID_BYTES = 128
+MI_PEER_HANDLE_BYTES = 64
 
 i64 = C.c_int64
 i64p = C.POINTER(C.c_int64)
@@ -72,6 +73,13 @@ SIGNATURES = {
     "mi_loopback_group_create": [C.c_int, C.POINTER(vp)],
     "mi_loopback_group_destroy": [vp],
     "mi_ctx_loopback_init": [vp, vp, C.c_int],
+    "mi_loopback_group_set_mode": [vp, C.c_int],
+    "mi_ctx_peer_init": [vp, C.c_int, C.c_int, i64],
+    "mi_ctx_peer_export": [vp, vp, C.POINTER(vp)],
+    "mi_ctx_peer_import": [vp, C.c_int, vp, vp],
+    "mi_ctx_peer_ready": [vp],
+    "mi_ctx_set_exchange": [vp, C.c_int],
+    "mi_ctx_query": [vp, C.c_int, i64p],
     "mi_assembly_plan_create": [vp, i64, i64, i64p, C.c_int, f64p, f64p, f64p, f64p, i64, i64, i64p, i64p, C.POINTER(vp)],
     "mi_assembly_run": [vp, vp, vp],
     "mi_assembly_plan_destroy": [vp],

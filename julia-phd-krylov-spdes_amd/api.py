@@ -125,6 +125,45 @@ class Context:
         check(self._L.mi_ctx_comm_init(self._h, buf, C.c_int(rank), C.c_int(n_ranks)))
         self.rank, self.n_ranks = rank, n_ranks
 
+    # -- the one-shot peer exchange (include/mi355schur.h; `@distributed (+)`, EllipticPdePllDomainDecomposition.jl:10-14)
+    def peer_init(self, rank: int, n_ranks: int, arena_bytes: int = 0) -> None:
+        check(self._L.mi_ctx_peer_init(self._h, C.c_int(rank), C.c_int(n_ranks), i64(arena_bytes)))
+        self.rank, self.n_ranks = rank, n_ranks
+
+    def peer_export(self):
+        """(handle bytes for other processes, arena base address for contexts of this process)"""
+        buf = C.create_string_buffer(_lib.MI_PEER_HANDLE_BYTES)
+        base = vp()
+        check(self._L.mi_ctx_peer_export(self._h, buf, C.byref(base)))
+        return buf.raw, int(base.value or 0)
+
+    def peer_import(self, rank: int, handle: bytes = None, same_process_base: int = 0) -> None:
+        buf = C.create_string_buffer(handle, _lib.MI_PEER_HANDLE_BYTES) if handle is not None else None
+        check(self._L.mi_ctx_peer_import(self._h, C.c_int(rank), buf, vp(same_process_base or None)))
+
+    def peer_ready(self) -> None:
+        check(self._L.mi_ctx_peer_ready(self._h))
+
+    def set_exchange(self, use_peer_exchange: bool) -> None:
+        check(self._L.mi_ctx_set_exchange(self._h, C.c_int(1 if use_peer_exchange else 0)))
+
+    def query(self, what: str) -> int:
+        """`mi_ctx_query`: "no_graph", "peer_exchange", "graph_replays", "exchanges"."""
+        out = i64(0)
+        check(self._L.mi_ctx_query(self._h, C.c_int({"no_graph": 0, "peer_exchange": 1, "graph_replays": 2, "exchanges": 3}[what]), C.byref(out)))
+        return int(out.value)
+
+    def peer_connect(self, rank: int, n_ranks: int, all_gather) -> None:
+        """Whole hand-shake over any transport: `all_gather(obj) -> list of every rank's obj` (e.g. a wrapper of
+        torch.distributed.all_gather_object)."""
+        self.peer_init(rank, n_ranks)
+        handle, _ = self.peer_export()
+        handles = all_gather(handle)
+        for q, h in enumerate(handles):
+            if q != rank:
+                self.peer_import(q, h)
+        self.peer_ready()
+
     def allreduce_sum(self, v):
         self._mode_for(v)
         keep, p = self._ptr(v, writable=True)
@@ -188,6 +227,10 @@ class LoopbackGroup:
         h = vp()
         check(L.mi_loopback_group_create(C.c_int(n), C.byref(h)))
         self._h, self._L, self.n = h, L, n
+
+    def set_mode(self, mode: int) -> None:
+        """0: device-side peer exchange when GPU_MAX_HW_QUEUES >= n (graphs); 1: host rendezvous (eager launches)."""
+        check(self._L.mi_loopback_group_set_mode(self._h, C.c_int(mode)))
 
     def __del__(self):
         try:

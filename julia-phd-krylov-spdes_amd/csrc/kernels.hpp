@@ -1116,7 +1116,11 @@ struct PcgFold {
   const int *peer;          // [nloc*W] local positions of the same Γ node in the sharing subdomains (-1 pad)
   const int *jrank;         // [nloc] rank of this subdomain among the contributors of the node (0 = owner)
   int W;
-  int part_rows;            // PHASE 0 writes its partial dot per row (local order, nloc entries) instead of per tile
+  int part_rows;            // this launch is sharded over ranks: partial dots per ROW (local order, nloc entries) instead of per tile
+  // inputs that come out of a peer exchange (exchange.hpp) are double-buffered by the parity of the exchange number:
+  // con_in / part_in0 / part_in1 point at copy 0, copy (*in_epoch & 1) is in_stride doubles further
+  const unsigned long long *in_epoch;
+  long long in_stride;
   // deflation (defcg.jl:291-305; nvec == 0: plain pcg). PHASE 1 also leaves per-tile partials of WtA*z; k_defl_mu turns
   // them into mu = WtAW \ (WtA*z) and (W*mu) in local order; PHASE 0 subtracts that from beta*p + z.
   int nvec;
@@ -1160,9 +1164,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   const int done0 = st->done;
   const long long it0 = st->it, it_nxt0 = st->it_nxt, maxit = st->maxit, cap = st->res_cap;
   const double tol = st->tol, rTz0 = st->rTz, old = st->rTz_prev;
+  const unsigned long long xe = f.in_epoch ? *f.in_epoch : 0ull;   // (same round trip as the state block)
   asm volatile("" ::"s"(t.mat_off), "s"(t.n), "s"(t.ld), "s"(t.loc_off), "s"(t.row0), "s"(t.active), "s"(t.nrows), "s"(it0),
-               "s"(it_nxt0), "s"(maxit), "s"(cap), "s"(tol), "s"(rTz0), "s"(old), "s"(done0));
+               "s"(it_nxt0), "s"(maxit), "s"(cap), "s"(tol), "s"(rTz0), "s"(old), "s"(done0), "s"(xe));
   if (done0) return;
+  const long long xoff = (long long)(xe & 1ull) * f.in_stride;
+  const double *con_in = f.con_in + xoff, *part_in0 = f.part_in0 + xoff, *part_in1 = PHASE == 0 ? f.part_in1 + xoff : nullptr;
   __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
   __shared__ double sm[2 * (NTH / 64)];
   __shared__ double rowv[NR], rowc0[NR], rowc1[NR];
@@ -1186,8 +1193,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int i = i0 + k * NTH;
-      ta[k] = i < f.n_in ? f.part_in0[i] : 0.0;
-      tb[k] = PHASE == 0 && i < f.n_in ? f.part_in1[i] : 0.0;
+      ta[k] = i < f.n_in ? part_in0[i] : 0.0;
+      tb[k] = PHASE == 0 && i < f.n_in ? part_in1[i] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) { pa += ta[k]; if (PHASE == 0) pb += tb[k]; }
@@ -1199,7 +1206,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     cv[q] = cs[q] = 0.0; cc[q] = PHASE == 1 ? 1.0 : 0.0;
     if (j < n) {
       const int loc = off + j;
-      cs[q] = slot_sum(f.con_in, loc, W);
+      cs[q] = slot_sum(con_in, loc, W);
       if (PHASE == 1) { cv[q] = first1 ? f.r_gamma[m.gidx[loc]] : f.r_cur[loc]; cc[q] = m.cnt[loc]; }
       else { cv[q] = f.p_cur[loc]; if (f.nvec > 0) cc[q] = f.wm_loc[loc]; }
     }
@@ -1337,10 +1344,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     }
   }
   __syncthreads();
-  // Multi-GPU, sharded S: a tile whose block lives on another rank has done its share of the vector work (scalars,
-  // owner stores of p / r) and stops here; its contribution rows and partial dot come from the owning rank through the
-  // all-reduce that follows the launch (its own entries stay zero).
-  if (PHASE == 0 && !t.active) return;  // (the host only shards the S launch; the ΠS launch needs all tiles)
+  // Multi-GPU, sharded operator: a tile whose block lives on another rank has done its share of the vector work (scalars,
+  // owner stores of p / r, x) and stops here; its contribution rows and partial dots come from the owning rank through the
+  // exchange that follows the launch (its own entries stay zero).
+  if (!t.active) {
+    if (PHASE == 1 && o_q >= 0 && o_own) f.x[o_g] = o_x + coef * o_a;  // x + alpha*p (cg.jl:97)
+    return;
+  }
   MI_FSTAMP(3);   // operand staged
   rows.panel(xs, 0, t.ld);
   MI_FSTAMP(4);   // stream consumed
@@ -1367,10 +1377,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   if (PHASE == 1 && o_q >= 0 && o_own) f.x[o_g] = o_x + coef * o_a;  // x + alpha*p (cg.jl:97), off the critical path
   __syncthreads();
   MI_FSTAMP(5);   // results scattered
-  if (PHASE == 0 && f.part_rows) {
-    // multi-GPU, sharded S: one product per ROW at its local position instead of one partial per tile — a layout that
-    // does not depend on how each rank tiles its blocks, so the ranks' arrays add up to the full one
-    if (threadIdx.x < NR && t.row0 + (int)threadIdx.x < n) f.part_out0[off + t.row0 + threadIdx.x] = rowc1[threadIdx.x];
+  if (f.part_rows) {
+    // multi-GPU, sharded launch: one product per ROW at its local position instead of one partial per tile — a layout that
+    // does not depend on how each rank tiles its blocks, so the ranks' arrays are a disjoint union of the full one
+    if (threadIdx.x < NR && t.row0 + (int)threadIdx.x < n) {
+      const int lr = off + t.row0 + (int)threadIdx.x;
+      if (PHASE == 0) f.part_out0[lr] = rowc1[threadIdx.x];                                   // p_g * Ap-contribution
+      else { f.part_out1[lr] = rowc1[threadIdx.x]; f.part_out0[lr] = rowc0[threadIdx.x]; }    // r_g * z-contribution; r_g^2 (owner rows)
+    }
     return;
   }
   if (PHASE == 1 && f.nvec > 0 && (int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + f.nvec) {

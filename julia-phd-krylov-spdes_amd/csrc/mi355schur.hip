@@ -1,6 +1,7 @@
 // extern "C" surface of libmi355schur (see include/mi355schur.h for the contract of every symbol).
 #include <dlfcn.h>
 
+#include <thread>
 #include <tuple>
 
 #include "eig_solvers.hpp"
@@ -186,6 +187,7 @@ static int run_init_solver(mi_op_t A, mi_op_t M, const double *b, double *x, con
   });
 }
 
+void peer_allreduce(PeerComm &p, const double *send, double *recv, size_t n, hipStream_t s) { p.allreduce(send, recv, n, s); }
 }  // namespace mi
 
 using namespace mi;
@@ -235,6 +237,7 @@ int mi_ctx_destroy(mi_ctx_t ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->workspaces.clear();
     if (ctx->comm) (void)Rccl::get().CommDestroy(ctx->comm);
+    delete ctx->peer;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MI_OK;
@@ -316,16 +319,143 @@ int mi_loopback_group_destroy(void *group) {
   if (!group) return MI_OK;
   LoopGroup *g = static_cast<LoopGroup *>(group);
   for (auto e : g->ready) if (e) (void)hipEventDestroy(e);
+  for (void *a : g->arena) if (a) (void)hipFree(a);
   delete g;
   return MI_OK;
+}
+static size_t peer_arena_default() {
+  const int mb = env_int("MI355_PEER_ARENA_MB", 64);
+  return (size_t)std::max(4, mb) << 20;
 }
 int mi_ctx_loopback_init(mi_ctx_t ctx, void *group, int rank) {
   LoopGroup *g = static_cast<LoopGroup *>(group);
   if (!ctx || !g || rank < 0 || rank >= g->n || ctx->comm) return fail(MI_ERR_BAD_ARG, "bad loopback arguments");
-  ctx->loop = g; ctx->rank = rank; ctx->n_ranks = g->n;
-  ctx->no_graph = true;  // the loopback collective synchronises with the host
-  for (auto &kv : ctx->workspaces) kv.second->drop_graphs();
+  return guarded([&]() -> int {
+    ctx->use();
+    ctx->loop = g; ctx->rank = rank; ctx->n_ranks = g->n;
+    for (auto &kv : ctx->workspaces) kv.second->drop_graphs();
+    // Device-side joining needs every rank's stream on a hardware queue of its own (a wait kernel at the head of a queue
+    // it shares with the kernel it waits for never ends; measured: 8 streams on the default 4 queues expire every wait,
+    // GPU_MAX_HW_QUEUES=16 runs them). Same answer on every rank: the environment is the process's.
+    const bool device_side = g->mode == 0 && g->n <= XCHG_MAX_RANKS && env_int("GPU_MAX_HW_QUEUES", 4) >= g->n &&
+                             !env_int("MI355_LOOPBACK_HOST", 0);
+    if (!device_side) {
+      ctx->no_graph = true;  // the host-rendezvous collective synchronises with the host
+      return MI_OK;
+    }
+    delete ctx->peer;
+    ctx->peer = new PeerComm();
+    ctx->peer->init(ctx->device, rank, g->n, peer_arena_default());
+    ctx->peer->owns_arena = false;                  // freed with the group: a rank that leaves early must not pull memory from under its peers' stores
+    g->arena[rank] = ctx->peer->arena;
+    g->barrier();                                   // every rank has published its arena
+    for (int q = 0; q < g->n; ++q) ctx->peer->import_peer(q, nullptr, g->arena[q]);
+    ctx->peer->finish();
+    ctx->peer_on = true;
+    ctx->no_graph = false;
+    // Trial exchanges with a short bound: the ranks lined up by the host, then STAGGERED, each exchange between an
+    // asynchronous copy in and one out — if two ranks' streams share a hardware queue (more live streams in the process
+    // than GPU_MAX_HW_QUEUES), or the runtime puts the ranks' copies on one engine queue (a copy that waits for a
+    // spinning kernel then blocks the next rank's copy in: measured with copies above GPU_FORCE_BLIT_COPY_SIZE), a wait
+    // expires here instead of in a solve, and the whole group falls back to the host rendezvous.
+    const long long keep = ctx->peer->peers.timeout;
+    ctx->peer->set_timeout_ms(env_int("MI355_PEER_SELFTEST_MS", 400));
+    const size_t trial = 16384;   // doubles: 128 KiB, above the runtime's default blit threshold
+    ctx->pin_b.ensure(trial);
+    DevBuf<double> tbuf(trial);
+    ctx->peer->reserve_stage(trial);
+    std::memset(ctx->pin_b.p, 0, trial * sizeof(double));
+    for (int k = 0; k < 3; ++k) {
+      g->barrier();
+      std::this_thread::sleep_for(std::chrono::milliseconds(3 * ((rank + k) % g->n)));
+      MI_HIP(hipMemcpyAsync(tbuf.p, ctx->pin_b.p, trial * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      ctx->peer->allreduce(tbuf.p, tbuf.p, trial, ctx->stream);
+      MI_HIP(hipMemcpyAsync(ctx->pin_b.p, tbuf.p, trial * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      MI_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    const int bad = ctx->peer->take_error(ctx->stream);
+    { std::lock_guard<std::mutex> lk(g->mu); g->selftest_failed += bad; }
+    g->barrier();
+    ctx->peer->peers.timeout = keep;
+    if (g->selftest_failed) {
+      ctx->peer_on = false;
+      ctx->no_graph = true;
+    }
+    g->barrier();
+    return MI_OK;
+  });
+}
+int mi_loopback_group_set_mode(void *group, int mode) {
+  if (!group || mode < 0 || mode > 1) return fail(MI_ERR_BAD_ARG, "bad loopback mode");
+  static_cast<LoopGroup *>(group)->mode = mode;
   return MI_OK;
+}
+
+// ---- the peer exchange (exchange.hpp)
+int mi_ctx_peer_init(mi_ctx_t ctx, int rank, int n_ranks, int64_t arena_bytes) {
+  if (!ctx || arena_bytes < 0) return fail(MI_ERR_BAD_ARG, "bad peer-exchange arguments");
+  return guarded([&]() -> int {
+    ctx->use();
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &kv : ctx->workspaces) kv.second->drop_graphs();
+    delete ctx->peer;
+    ctx->peer = nullptr; ctx->peer_on = false;
+    ctx->peer = new PeerComm();
+    ctx->peer->init(ctx->device, rank, n_ranks, arena_bytes ? (size_t)arena_bytes : peer_arena_default());
+    if (!ctx->comm) { ctx->rank = rank; ctx->n_ranks = n_ranks; }
+    else if (ctx->rank != rank || ctx->n_ranks != n_ranks) raise(MI_ERR_BAD_ARG, "peer exchange: rank %d of %d differs from the communicator's %d of %d", rank, n_ranks, ctx->rank, ctx->n_ranks);
+    return MI_OK;
+  });
+}
+int mi_ctx_peer_export(mi_ctx_t ctx, void *handle_out, void **base_out) {
+  if (!ctx || !ctx->peer || (!handle_out && !base_out)) return fail(MI_ERR_BAD_ARG, "peer exchange not initialised, or nothing to export into");
+  return guarded([&]() -> int {
+    ctx->use();
+    if (handle_out) ctx->peer->export_handle(handle_out);
+    if (base_out) *base_out = ctx->peer->arena;
+    return MI_OK;
+  });
+}
+int mi_ctx_peer_import(mi_ctx_t ctx, int rank, const void *handle, void *same_process_base) {
+  if (!ctx || !ctx->peer) return fail(MI_ERR_BAD_ARG, "peer exchange not initialised");
+  return guarded([&]() -> int { ctx->use(); ctx->peer->import_peer(rank, handle, same_process_base); return MI_OK; });
+}
+int mi_ctx_peer_ready(mi_ctx_t ctx) {
+  if (!ctx || !ctx->peer) return fail(MI_ERR_BAD_ARG, "peer exchange not initialised");
+  return guarded([&]() -> int { ctx->use(); ctx->peer->finish(); ctx->peer_on = true; return MI_OK; });
+}
+int mi_ctx_query(mi_ctx_t ctx, int what, int64_t *out) {
+  if (!ctx || !out) return fail(MI_ERR_BAD_ARG, "bad query arguments");
+  return guarded([&]() -> int {
+    ctx->use();
+    switch (what) {
+      case MI_QUERY_NO_GRAPH: *out = ctx->no_graph ? 1 : 0; break;
+      case MI_QUERY_PEER_EXCHANGE: *out = ctx->use_peer() ? (ctx->peer->fine_grained ? 2 : 1) : 0; break;
+      case MI_QUERY_GRAPH_REPLAYS: *out = ctx->n_replays; break;
+      case MI_QUERY_EXCHANGES: {
+        unsigned long long e = 0;
+        if (ctx->peer) {
+          MI_HIP(hipStreamSynchronize(ctx->stream));
+          memcpy_sync(&e, &ctx->peer->st->epoch, sizeof e, hipMemcpyDeviceToHost);
+        }
+        *out = (int64_t)e;
+        break;
+      }
+      default: return fail(MI_ERR_BAD_ARG, "unknown query %d", what);
+    }
+    return MI_OK;
+  });
+}
+int mi_ctx_set_exchange(mi_ctx_t ctx, int use_peer_exchange) {
+  if (!ctx) return fail(MI_ERR_BAD_ARG, "ctx is NULL");
+  if (use_peer_exchange && (!ctx->peer || !ctx->peer->ready)) return fail(MI_ERR_BAD_ARG, "peer exchange not ready");
+  return guarded([&]() -> int {
+    ctx->use();
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &kv : ctx->workspaces) kv.second->drop_graphs();
+    ctx->peer_on = use_peer_exchange != 0;
+    return MI_OK;
+  });
 }
 
 int mi_ctx_comm_destroy(mi_ctx_t ctx) {
@@ -345,8 +475,10 @@ int mi_ctx_allreduce_sum(mi_ctx_t ctx, double *buf, int64_t n) {
   return guarded([&]() -> int {
     ctx->use();
     InOut v(ctx, buf, (size_t)n, ctx->scratch_a, true);
-    ctx->allreduce(v.dev, (size_t)n);  // RCCL or the in-process loopback group; a no-op without a communicator
+    ctx->allreduce(v.dev, (size_t)n);  // RCCL, the peer exchange or the in-process group's host rendezvous; a no-op without a communicator
     v.finish();
+    if (ctx->use_peer() && !ctx->comm && ctx->peer->take_error(ctx->stream))
+      raise(MI_ERR_COMM, "peer exchange: a wait for the other ranks expired (MI355_PEER_TIMEOUT_MS): %s", ctx->peer->err_text.c_str());
     return MI_OK;
   });
 }
@@ -448,17 +580,28 @@ int mi_op_apply(mi_op_t op, const double *x, double *y) {
     }
     // Host pointers (the reference's own Julia loop calling mul! / \ every iteration): through pinned buffers, so both
     // copies are plain DMA transfers instead of the runtime's staged pageable copies.
+    static const bool trace = env_int("MI355_TRACE", 0) != 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto tr = [&](const char *what) {
+      if (trace) std::fprintf(stderr, "[trace rank %d] mi_op_apply %-22s +%.3f s\n", c->rank, what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    };
     c->pin_b.ensure(n); c->pin_x.ensure(n);
+    tr("pinned buffers");
     op->hx.ensure(n); op->hy.ensure(n);
+    tr("device buffers");
     std::memcpy(c->pin_b.p, x, n * sizeof(double));
     MI_HIP(hipMemcpyAsync(op->hx.p, c->pin_b.p, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    tr("H2D enqueued");
     if (c->has_comm() || !op->impl->writes_y_once()) {  // a collective or read-modify-write kernels touch y: keep it in device memory
       op->impl->apply(op->hx.p, op->hy.p, nullptr);
+      tr("apply enqueued");
       MI_HIP(hipMemcpyAsync(c->pin_x.p, op->hy.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      tr("D2H enqueued");
     } else {
       op->impl->apply(op->hx.p, c->pin_x.p, nullptr);  // the last kernel of the apply writes y straight into pinned memory
     }
     MI_HIP(hipStreamSynchronize(c->stream));
+    tr("synchronised");
     std::memcpy(y, c->pin_x.p, n * sizeof(double));
     return MI_OK;
   });
@@ -817,7 +960,7 @@ int mi_schur_setup_run(mi_setup_t plan, const double *ii_val, const double *ig_v
     if (c->ptr_mode != MI_PTR_DEVICE) {   // host mode is synchronous: a Cholesky that met a non-positive pivot is reported
       for (auto &l : plan->lanes) {
         int info[2] = {0, 0};
-        MI_HIP(hipMemcpy(info, l.info.p, sizeof info, hipMemcpyDeviceToHost));
+        memcpy_sync(info, l.info.p, sizeof info, hipMemcpyDeviceToHost);
         if (info[0] || info[1]) return fail(MI_ERR_SINGULAR, "mi_schur_setup_run: an interior block is not positive definite (potrf info %d / %d)", info[0], info[1]);
       }
     }

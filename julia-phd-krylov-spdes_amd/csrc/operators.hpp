@@ -7,6 +7,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "assembly.hpp"
+#include "exchange.hpp"
 
 namespace mi {
 
@@ -221,6 +222,7 @@ struct LocalMaps {
   DevBuf<int> gidx, aptr, apos, out_pos;
   bool sharded = false;  // only a slice of the subdomains lives here and a communicator exists: Γ-sums are all-reduced
   DevBuf<int> jrank, peer, tgt;  // local-order bookkeeping of the folded PCG launches (kernels.hpp PcgFold)
+  std::vector<int> tgt_h;        // host copy of tgt (the peer exchange lists a rank's own table entries from it)
   int slot_width = 1;  // W: contribution slots per Γ node (max multiplicity over this rank's subdomains)
   void build(mi_ctx_s *c, int64_t ndom, int64_t n_gamma, const int64_t *n_gamma_d, const int64_t *const *gather_idx,
              int base, int64_t d0, int64_t d1) {
@@ -305,6 +307,9 @@ struct LocalMaps {
       }
     }
     jrank.upload(jr, c->stream); peer.upload(pe, c->stream); tgt.upload(tg, c->stream);
+    tgt_h = tg;
+    // sums over ranks that this operator will issue inside captured graphs need their staging before the capture
+    if (sharded && c->use_peer()) c->peer->reserve_stage((size_t)n_gamma * (size_t)std::max(slot_width, 1) + 4);
   }
   void assemble(mi_ctx_s *c, int64_t n_gamma, const double *yloc, double *y, const int *done) const {
     hipLaunchKernelGGL(k_assemble, dim3(vec_grid(n_gamma)), dim3(NT), 0, c->stream, (int)n_gamma, aptr.p, apos.p, yloc,
@@ -328,9 +333,21 @@ struct DenseBlockOp : Operator {
   // r/p current+next copies
   DevBuf<double> fold_pack, fold_pack_all, fold_part1, fold_vec;
   size_t fold_con_n = 0, fold_pack_n = 0;
-  double *fold_con(bool reduced = false) const { return (reduced ? fold_pack_all.p : fold_pack.p); }
-  double *fold_part0(bool reduced = false) const { return (reduced ? fold_pack_all.p : fold_pack.p) + fold_con_n; }
-  void reduce_fold() { ctx->allreduce(fold_pack.p, fold_pack_all.p, fold_pack_n); }
+  size_t fold_p1_off = 0;         // sharded Neumann-Neumann blocks: the second partial array (r'z) sits in the pack too
+  // Peer exchange (exchange.hpp): the reduced pack is a double-buffered table at offset xt_off of every rank's arena;
+  // own_idx lists the pack entries this rank's launches produce (contribution slots and per-row partials of its rows).
+  bool xt_on = false;
+  size_t xt_off = 0, xt_copy = 0;
+  DevBuf<int> own_idx;
+  int n_own = 0;
+  double *fold_reduced() const { return xt_on ? ctx->peer->local(xt_off) : fold_pack_all.p; }   // (peer: copy 0; the launches add the parity)
+  double *fold_con(bool reduced = false) const { return (reduced ? fold_reduced() : fold_pack.p); }
+  double *fold_part0(bool reduced = false) const { return (reduced ? fold_reduced() : fold_pack.p) + fold_con_n; }
+  double *fold_part1p(bool reduced = false) const { return fold_p1_off ? (reduced ? fold_reduced() : fold_pack.p) + fold_p1_off : fold_part1.p; }
+  void reduce_fold() {
+    if (xt_on) ctx->peer->push(xt_off, xt_copy, fold_pack.p, own_idx.p, n_own, ctx->stream, nullptr);
+    else ctx->allreduce(fold_pack.p, fold_pack_all.p, fold_pack_n);
+  }
   DevBuf<GemvTile> tiles;
   std::vector<long long> moff_h;  // per local subdomain: element offset of its block in M (row-major, ld_h[dl])
   std::vector<int> ld_h;
@@ -401,7 +418,7 @@ struct DenseBlockOp : Operator {
     // (+ one zeroed panel behind the last block: the persistent kernel reads whole 128-double groups of a row without
     // clamping, so a read may run past a row's end — into the next row, or into this tail — and meets a zero operand there)
     M.alloc((size_t)tot + GEMV_PANEL);
-    MI_HIP(hipMemset(M.p + tot, 0, sizeof(double) * GEMV_PANEL));
+    memset_sync(M.p + tot, 0, sizeof(double) * GEMV_PANEL);
     // column-major (Julia) -> padded row-major, one block at a time
     for (int dl = 0; dl < maps.ndl; ++dl) {
       if (!owned(dl)) continue;
@@ -411,7 +428,7 @@ struct DenseBlockOp : Operator {
       for (int j = 0; j < n_d; ++j)
         for (int i = 0; i < n_d; ++i) rowm[(size_t)i * l + j] = src[(size_t)i + (size_t)j * n_d];
       if (!rowm.empty())
-        MI_HIP(hipMemcpy(M.p + moff[dl], rowm.data(), rowm.size() * sizeof(double), hipMemcpyHostToDevice));
+        memcpy_sync(M.p + moff[dl], rowm.data(), rowm.size() * sizeof(double), hipMemcpyHostToDevice);
     }
     if (scale) {
       std::vector<double> cv(maps.nloc);
@@ -429,10 +446,36 @@ struct DenseBlockOp : Operator {
     yslots_all.zero(c->stream);
     // contributions and first partial-dot array share one buffer: the sharded S launch all-reduces both in one call
     fold_con_n = (size_t)maps.nloc * maps.slot_width + 4;
-    fold_pack_n = fold_con_n + std::max<size_t>((size_t)ntiles + 1, (size_t)maps.nloc + 1);  // per-tile, or per-row when sharded
+    const size_t part_n = std::max<size_t>((size_t)ntiles + 1, (size_t)maps.nloc + 1);    // per-tile, or per-row when sharded
+    fold_pack_n = fold_con_n + part_n;
+    if (reduce_over_ranks && full_maps && scale) { fold_p1_off = fold_pack_n; fold_pack_n += (size_t)maps.nloc + 1; }  // r'z per row, exchanged with the rest
     fold_pack.alloc(fold_pack_n); fold_pack.zero(c->stream);
     fold_pack_all.alloc(fold_pack_n); fold_pack_all.zero(c->stream);
     fold_part1.alloc((size_t)ntiles + 1); fold_part1.zero(c->stream);
+    if (reduce_over_ranks && c->use_peer()) {
+      // staging of the generic sums this operator issues (plain applies: the slot table), reserved outside any capture
+      c->peer->reserve_stage(std::max<size_t>(fold_pack_n, (size_t)n_gamma * maps.slot_width + 4));
+      if (full_maps) {
+        // the folded launches' table: entries this rank produces = the contribution slots its rows write (tgt) and the
+        // per-row partials of its rows
+        std::vector<int> own;
+        const int W = maps.slot_width;
+        for (int dl = 0; dl < maps.ndl; ++dl) {
+          if (!owned(dl)) continue;
+          for (int l = 0; l < maps.nd[dl]; ++l) {
+            const int loc = maps.loc_off[dl] + l;
+            for (int k = 0; k < W; ++k) { const int tg = maps.tgt_h[(size_t)loc * W + k]; if (tg >= 0) own.push_back(tg); }
+            own.push_back((int)fold_con_n + loc);
+            if (fold_p1_off) own.push_back((int)fold_p1_off + loc);
+          }
+        }
+        n_own = (int)own.size();
+        own_idx.upload(own, c->stream);
+        xt_copy = (fold_pack_n + 31) & ~(size_t)31;
+        xt_off = c->peer->alloc(2 * xt_copy * sizeof(double));   // (zero since the arena was created: a bump allocator never re-uses)
+        xt_on = true;
+      }
+    }
     fold_vec.alloc((size_t)maps.nloc * 4 + 4); fold_vec.zero(c->stream);
     MI_HIP(hipStreamSynchronize(c->stream));
     meta = DenseMeta{M.p, tiles.p, maps.gidx.p, scale ? cnt.p : nullptr, maps.out_pos.p};
@@ -659,8 +702,8 @@ struct InteriorCg {
     {
       std::vector<int> bdh(A.nblocks), nih(ndl);
       MI_HIP(hipStreamSynchronize(s));
-      MI_HIP(hipMemcpy(bdh.data(), blk_dom.p, sizeof(int) * A.nblocks, hipMemcpyDeviceToHost));
-      MI_HIP(hipMemcpy(nih.data(), n_i.p, sizeof(int) * ndl, hipMemcpyDeviceToHost));
+      memcpy_sync(bdh.data(), blk_dom.p, sizeof(int) * A.nblocks, hipMemcpyDeviceToHost);
+      memcpy_sync(nih.data(), n_i.p, sizeof(int) * ndl, hipMemcpyDeviceToHost);
       std::vector<IcgBlkInfo> bi(A.nblocks);
       for (int b = 0; b < A.nblocks; ++b) {
         const int d = bdh[b];

@@ -418,7 +418,7 @@ inline void gj_build(mi_setup_s &P) {
     off_y[d] = take(nm); off_g0[d] = take(nm); off_g1[d] = take(nm); off_P[d] = take(2 * GJ_B * GJ_B);
   }
   G->pool.alloc(tot + 32);
-  MI_HIP(hipMemset(G->pool.p, 0, sizeof(double) * (tot + 32)));
+  memset_sync(G->pool.p, 0, sizeof(double) * (tot + 32));
   G->dom_h.resize(P.ndom);
   for (int d = 0; d < P.ndom; ++d) {
     const SetupDom &D = P.dom[d];

@@ -177,7 +177,7 @@ struct SolverWorkspace {
     const size_t vec = pad(sizeof(double) * ((size_t)n + 2)), part = pad(sizeof(double) * MAX_PARTS);
     const size_t total = pad(sizeof(SolverState)) + 4 * part + 6 * vec;
     slab.alloc(total);
-    MI_HIP(hipMemset(slab.p, 0, total));
+    memset_sync(slab.p, 0, total);
     char *q = slab.p;
     st = (SolverState *)q; q += pad(sizeof(SolverState));
     part_pAp = (double *)q; q += part; part_rr = (double *)q; q += part;
@@ -187,9 +187,9 @@ struct SolverWorkspace {
     MI_HIP(hipHostMalloc((void **)&flags, 2 * sizeof(PinnedFlags)));
     std::memset(flags, 0, 2 * sizeof(PinnedFlags));
     MI_HIP(hipHostMalloc((void **)&args, sizeof(SolveArgs)));
-    if (env_int("MI355_FOLD_DEBUG", 0)) { fold_dbg.alloc(512); MI_HIP(hipMemset(fold_dbg.p, 0, 512 * sizeof(long long))); }
+    if (env_int("MI355_FOLD_DEBUG", 0)) { fold_dbg.alloc(512); memset_sync(fold_dbg.p, 0, 512 * sizeof(long long)); }
     args_dev.alloc(1); end_count.alloc(1);
-    MI_HIP(hipMemset(end_count.p, 0, sizeof(unsigned)));
+    memset_sync(end_count.p, 0, sizeof(unsigned));
     MI_HIP(hipHostMalloc((void **)&res_stage, RES_STAGE * sizeof(double)));
     for (auto &e : ev) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
@@ -299,7 +299,9 @@ struct Krylov {
       Ad = A->as_dense(); Md = M->as_dense();
       // multi-GPU: S may be sharded (built on the maps of all subdomains, inactive tiles for the other ranks' blocks)
       // while the Neumann-Neumann blocks are replicated: the S launch is then followed by one all-reduce
-      fold = Ad && Md && (!Ad->reduce_over_ranks || (Ad->full_maps && nvec == 0)) && !Md->reduce_over_ranks &&
+      // ... or sharded as well (both on the maps of all subdomains): then the ΠS launch is followed by an exchange too
+      fold = Ad && Md && (!Ad->reduce_over_ranks || (Ad->full_maps && nvec == 0)) &&
+             (!Md->reduce_over_ranks || (Md->full_maps && Md->fold_p1_off && nvec == 0 && !env_int("MI355_NO_FOLD_SHARDED_NN", 0))) &&
              !Ad->scale && Md->scale && Ad->same_maps(*Md) && Ad->ntiles > 0 && Ad->max_ld <= GEMV_PANEL && Ad->maps.slot_width <= 4 &&
              (Ad->max_ld + 64 * Ad->waves - 1) / (64 * Ad->waves) <= 8 && (Md->max_ld + 64 * Md->waves - 1) / (64 * Md->waves) <= 8;
     }
@@ -322,21 +324,25 @@ struct Krylov {
     f.r_cur = Ad->fold_vec.p; f.r_nxt = f.r_cur + nl; f.p_cur = f.r_nxt + nl; f.p_nxt = f.p_cur + nl;
     f.tgt = Ad->maps.tgt.p; f.peer = Ad->maps.peer.p; f.jrank = Ad->maps.jrank.p;
     // partial-dot arrays of the OTHER operator's launch (tilings may differ); a sharded S writes one product per row
-    f.part_rows = Ad->reduce_over_ranks ? 1 : 0;
+    f.part_rows = (phase ? Md->reduce_over_ranks : Ad->reduce_over_ranks) ? 1 : 0;   // layout of THIS launch's partial dots
     f.nvec = nvec; f.n_gamma = n;
     if (nvec > 0) { f.AW = ws.AW.p; f.part_mu = ws.fold_mu.p; f.wm_loc = ws.fold_wm.p; }
     if (capture_whole && phase == 0) { f.exit_args = ws.args_dev.p; f.exit_flags = &ws.flags[0]; }
     if (ws.fold_dbg.p) { f.dbg = ws.fold_dbg.p; f.dbg_wg = env_int("MI355_FOLD_DEBUG_WG", 0); }
-    f.n_in = phase ? (f.part_rows ? Ad->maps.nloc : Ad->ntiles) : Md->ntiles;
-    const bool red = Ad->reduce_over_ranks;  // the S launch's outputs are summed over the ranks before the ΠS launch reads them
+    // a sharded launch's outputs are exchanged over the ranks before the other launch reads them (reduced copy of the pack;
+    // with the peer exchange a double-buffered table whose parity the reading launch takes from the exchange counter)
+    const bool redA = Ad->reduce_over_ranks, redM = Md->reduce_over_ranks;
+    f.n_in = phase ? (redA ? Ad->maps.nloc : Ad->ntiles) : (redM ? Md->maps.nloc : Md->ntiles);
     if (phase) {  // ΠS launch: reads S contributions + partial p'Ap, writes ΠS contributions + partial r'r, r'z
-      f.con_in = Ad->fold_con(red); f.con_out = Md->fold_con();
-      f.part_in0 = Ad->fold_part0(red); f.part_in1 = nullptr;
-      f.part_out0 = Md->fold_part0(); f.part_out1 = Md->fold_part1.p;
+      f.con_in = Ad->fold_con(redA); f.con_out = Md->fold_con();
+      f.part_in0 = Ad->fold_part0(redA); f.part_in1 = nullptr;
+      f.part_out0 = Md->fold_part0(); f.part_out1 = Md->fold_part1p();
+      if (redA && Ad->xt_on) { f.in_epoch = &ctx->peer->st->epoch; f.in_stride = (long long)Ad->xt_copy; }
     } else {      // S launch: reads ΠS contributions + partial r'r, r'z, writes S contributions + partial p'Ap
-      f.con_in = Md->fold_con(); f.con_out = Ad->fold_con();
-      f.part_in0 = Md->fold_part0(); f.part_in1 = Md->fold_part1.p;
+      f.con_in = Md->fold_con(redM); f.con_out = Ad->fold_con();
+      f.part_in0 = Md->fold_part0(redM); f.part_in1 = Md->fold_part1p(redM);
       f.part_out0 = Ad->fold_part0(); f.part_out1 = nullptr;
+      if (redM && Md->xt_on) { f.in_epoch = &ctx->peer->st->epoch; f.in_stride = (long long)Md->xt_copy; }
     }
     return f;
   }
@@ -391,6 +397,7 @@ struct Krylov {
     if (fold) {
       // 2 launches per iteration: (alpha, x, r, z, r'z, r'r) in the ΠS GEMV; (stop rule, beta, p, Ap, p'Ap) in the S GEMV
       Md->gemv_pcg(1, fold_args(1));
+      if (Md->reduce_over_ranks) Md->reduce_fold();  // ΠS contributions + partial r'r, r'z: union over the ranks
       if (nvec > 0) {  // mu = WtAW \ (WtA * z); W*mu in local order for the S launch (defcg.jl:301-303)
         hipLaunchKernelGGL(k_defl_mu, dim3((Ad->maps.nloc + 1023) / 1024), dim3(1024), 0, s, ws.st, nvec, Md->ntiles, ws.fold_mu.p,
                            ws.LU.p, ws.piv.p, ws.W.p, (long long)n, Ad->maps.nloc, Ad->maps.gidx.p, ws.fold_wm.p, ws.mu.p, ws.fold_wloc.p);
@@ -687,6 +694,11 @@ struct Krylov {
   int solve(const double *b_in, double *x_io, const double *W_in, int64_t maxit, double eps, double *res_host,
             int64_t res_cap, int64_t *it_out) {
     int64_t cap_dev = 0;
+    struct AbortFlag {   // peer exchange: a wait that expires during this solve sets the stop flag (no iterating on garbage up to maxit)
+      mi_ctx_s *c; hipStream_t s;
+      AbortFlag(mi_ctx_s *c_, hipStream_t s_, int *flag) : c(c_), s(s_) { if (c->use_peer()) c->peer->set_abort_flag(flag, s); }
+      ~AbortFlag() { if (c->use_peer()) { c->peer->set_abort_flag(nullptr, s); (void)hipStreamSynchronize(s); } }
+    } abort_flag(ctx, s, &ws.st->done);
     bool use_graph = ctx->chunk > 0 && A->graph_safe() && (!M || M->graph_safe()) && !ctx->no_graph;
     // Undeflated solves on one GPU: entry kernel, set-up, iterations and exit kernel are ONE graph replay whose per-call
     // arguments travel through a pinned block, and the host waits for the exit kernel's last store instead of the stream.
@@ -721,7 +733,7 @@ struct Krylov {
       MI_HIP(hipStreamSynchronize(s));
       if (debug) {  // wall-clock stamps (100 MHz) of one workgroup: 5 for the set-up, then 8 per iteration
         std::vector<long long> h(512);
-        MI_HIP(hipMemcpy(h.data(), dbg.p, 512 * sizeof(long long), hipMemcpyDeviceToHost));
+        memcpy_sync(h.data(), dbg.p, 512 * sizeof(long long), hipMemcpyDeviceToHost);
         const ResTile &tt = rp->tiles_h[ra.dbg_wg];
         std::fprintf(stderr, "[resident] wg %d: n=%d ld=%d rows=%d U=%d regS=%d regP=%d ldsS=%d ldsP=%d resident_frac=%.3f\n", ra.dbg_wg, tt.n,
                      tt.ld, tt.nrows, tt.U, RES_WAVES * res_slots_S(tt.U), RES_WAVES * res_slots_P(tt.U), tt.ldsS, tt.ldsP, rp->resident_frac);   // (+8 rows per operator in the streaming slot)
@@ -766,7 +778,7 @@ struct Krylov {
         const unsigned long long seq = ++ws.seq;
         *ws.args = SolveArgs{b_in, x_io, x_io, spec_res ? ws.res_stage : (double *)nullptr, eps, (long long)maxit, (long long)cap_dev,
                              (long long)ncap, seq};
-        MI_HIP(hipGraphLaunch(g0, s));
+        ++ctx->n_replays; MI_HIP(hipGraphLaunch(g0, s));
         wait_seq(seq);
         if (ws.flags[0].respec) {   // x0 was not zero after all: the general form, and no such guess next time
           zero_variant = false;
@@ -774,7 +786,7 @@ struct Krylov {
           g0 = graph(-(int)first, 1);
           const unsigned long long seq2 = ++ws.seq;
           ws.args->seq = seq2;
-          MI_HIP(hipGraphLaunch(g0, s));
+          ++ctx->n_replays; MI_HIP(hipGraphLaunch(g0, s));
           wait_seq(seq2);
         }
         if (fold) ws.zero_x0[pk] = ws.flags[0].x0z != 0;
@@ -782,7 +794,7 @@ struct Krylov {
         if (ws.fold_dbg.p && fold) {   // stamps of the solve that has just finished (100 MHz ticks -> us since the first one)
           std::vector<long long> h(512);
           MI_HIP(hipStreamSynchronize(s));
-          MI_HIP(hipMemcpy(h.data(), ws.fold_dbg.p, 512 * sizeof(long long), hipMemcpyDeviceToHost));
+          memcpy_sync(h.data(), ws.fold_dbg.p, 512 * sizeof(long long), hipMemcpyDeviceToHost);
           const long long t0 = h[0] ? h[0] : ws.flags[0].t_entry;
           std::fprintf(stderr, "[fold stamps] wg %d, entry kernel at %.2f us\n", env_int("MI355_FOLD_DEBUG_WG", 0), (ws.flags[0].t_entry - t0) * 0.01);
           for (int r = 0; r < 64 && h[r * 8]; ++r) {
@@ -790,10 +802,10 @@ struct Krylov {
             for (int k = 0; k < 7; ++k) std::fprintf(stderr, " %8.2f", h[r * 8 + k] ? (h[r * 8 + k] - t0) * 0.01 : -1.0);
             std::fprintf(stderr, "\n");
           }
-          MI_HIP(hipMemset(ws.fold_dbg.p, 0, 512 * sizeof(long long)));
+          memset_sync(ws.fold_dbg.p, 0, 512 * sizeof(long long));
         }
       } else {
-        MI_HIP(hipGraphLaunch(g0, s));
+        ++ctx->n_replays; MI_HIP(hipGraphLaunch(g0, s));
         enqueue_results(0);
         MI_HIP(hipStreamSynchronize(s));
       }
@@ -804,7 +816,7 @@ struct Krylov {
         bool stop = false;
         fetch_flags(slot);
         for (int64_t l = 0; l < max_launch && !stop; ++l) {
-          MI_HIP(hipGraphLaunch(ex, s));
+          ++ctx->n_replays; MI_HIP(hipGraphLaunch(ex, s));
           const int prev = slot;
           slot ^= 1;
           fetch_flags(slot);
@@ -829,6 +841,8 @@ struct Krylov {
       MI_HIP(hipStreamSynchronize(s));
     }
     const long long it = ws.flags[0].it;
+    if (ctx->use_peer() && ctx->peer->take_error(s))
+      raise(MI_ERR_COMM, "peer exchange: a wait for the other ranks expired (MI355_PEER_TIMEOUT_MS): %s; the iterates of this solve are not valid", ctx->peer->err_text.c_str());
     if (!ws.flags[0].done) raise(MI_ERR_HIP, "internal: Krylov loop ended without the stop flag (it=%lld)", it);
     const int64_t ncopy = std::min<int64_t>(it, ncap);
     if (res_host && ncopy > 0) {

@@ -1,6 +1,15 @@
 import os
 import sys
 
+# In-process ranks (tests/test_gpu_multirank.py, test_gpu_parity.py) join their contexts by device-side flags: kernels of
+# one rank wait for kernels of another, which needs a hardware queue per rank (include/mi355schur.h, mi_ctx_loopback_init).
+# The HIP runtime reads this once, at its first call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# ... and the ranks' host<->device copies must not share an engine queue: a copy that waits for a spinning kernel would
+# block the next rank's copy in (measured at copies above the runtime's blit threshold): copies as kernels on each
+# rank's own stream. One process per GPU (the production layout) needs neither setting.
+os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "1048576")
+
 import numpy as np
 import pytest
 
@@ -85,6 +94,13 @@ def lowest_eigvecs(orc_op, n, nev):
     S = np.column_stack([orc_op(e) for e in np.eye(n)])
     w, V = np.linalg.eigh((S + S.T) / 2)
     return np.asfortranarray(V[:, :nev])
+
+
+@pytest.fixture(scope="session")
+def full(fem):
+    """Config 3 / 4 at BASELINE.json's full size: N=1000 (996 004 free DoF), 4x2 subdomains, lognormal coefficient."""
+    mesh = fem.get_mesh(1000)
+    return fem.build_schur_problem(1000, 4, 2, lognormal_coeff(fem, mesh.points), f_m1, u0734)
 
 
 @pytest.fixture(scope="session")

@@ -9,12 +9,6 @@ from conftest import f_m1, lognormal_coeff, u0734
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def full(fem):
-    mesh = fem.get_mesh(1000)
-    return fem.build_schur_problem(1000, 4, 2, lognormal_coeff(fem, mesh.points), f_m1, u0734)
-
-
 def test_full_size_pcg_matches_oracle(pkg, ctx, orc, full):
     P, api = full, pkg.api
     n, b = P.sub.n_Γ, P.b_schur

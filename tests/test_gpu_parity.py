@@ -683,6 +683,10 @@ def test_sharded_operators_with_in_process_ranks(pkg, orc, fem, world, replicate
     gi, cnt = P.sub.gather_idx, P.sub.node_Γ_cnt
     group = api.LoopbackGroup(world)
     out, errs = [None] * world, []
+    # NN blocks sharded too: here the 4-launch loop (bit-identical to the same loop on one context); the folded form with
+    # an exchange behind both launches is tests/test_gpu_multirank.py's
+    if not replicate_precond:
+        os.environ["MI355_NO_FOLD_SHARDED_NN"] = "1"
 
     def rank_main(r):
         try:
@@ -712,6 +716,7 @@ def test_sharded_operators_with_in_process_ranks(pkg, orc, fem, world, replicate
         t.start()
     for t in threads:
         t.join(timeout=300)
+    os.environ.pop("MI355_NO_FOLD_SHARDED_NN", None)
     assert not errs, errs
     assert all(o is not None for o in out), "a rank did not finish"
     for r in range(1, world):                                    # ranks stay bit-identical

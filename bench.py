@@ -12,8 +12,9 @@ counts from 1, so a solve that returns `it` ran it-1 iterations). Inputs (S_d, Î
 device before the timed region starts; the timed region is K solves bracketed by barrier + sync.
 
 At N>1 the 8 subdomains are split across ranks (8/N each), Î“-vectors are replicated and the two
-Î“-sums of every iteration are RCCL all-reduces captured inside the iteration graph; total work is
-fixed, so scaling is "strong".
+Î“-sums of every iteration are captured inside the iteration graph: the one-shot peer exchange (peer stores over
+xGMI + flags, csrc/exchange.hpp) when every rank can map its peers' arenas, RCCL all-reduces otherwise (`--exchange`);
+total work is fixed, so scaling is "strong".
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (batched dense GEMV of the S-apply,
 HIP events on the library's stream) and `cpu_baseline` (the C oracle, OpenMP over the host cores,
@@ -142,6 +143,12 @@ def secondary_measurements(args, api, fem, ctx, S, M, b_dev, n_Î“, ndom, bytes_i
         return float(np.median(ts)), last
 
     def entry(name, solve_full, solve_short, short_it, bytes_per_iter, extra=None):
+        try:    # a side measurement must not take the headline line down
+            _entry(name, solve_full, solve_short, short_it, bytes_per_iter, extra)
+        except Exception as e:   # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    def _entry(name, solve_full, solve_short, short_it, bytes_per_iter, extra=None):
         t_full, r = timed(solve_full)
         it = r[1]
         e = {"it": it, "iterations_per_s": round((it - 1) / (t_full * 1e-3), 1), "ms_per_solve": round(t_full, 4)}
@@ -155,24 +162,43 @@ def secondary_measurements(args, api, fem, ctx, S, M, b_dev, n_Î“, ndom, bytes_i
         out[name] = e
 
     z = lambda: torch.zeros(n_Î“, dtype=torch.float64, device="cuda")   # noqa: E731
-    # W: least-dominant eigenvectors of the assembled S (dense eigh on the device stands in for KrylovKit, Example03:209)
-    eye = torch.eye(n_Î“, dtype=torch.float64, device="cuda")
-    Sd = torch.stack([S.apply(eye[k].contiguous()) for k in range(n_Î“)], dim=1)
-    ctx.synchronize()
+    # W: least-dominant eigenvectors of the assembled S (a dense symmetric eigensolver stands in for KrylovKit, Example03:209).
+    # On the HOST (LAPACK, untimed set-up): the device route went through rocSOLVER's dsyevd, which faults under
+    # `rocprofv3 --pmc` (profiles/r02_pmc_crash_stack.txt) â€” the default command issues no rocSOLVER call any more.
     nvec_def = ndom + 10
-    W = torch.linalg.eigh((Sd + Sd.T) / 2)[1][:, :nvec_def].T.contiguous().T      # n x nvec, column-major
-    del Sd, eye
     vec_bytes = lambda nv: 2 * nv * n_Î“ * 8                                       # noqa: E731  WtA*z and W*mu streams
-    entry(f"defpcg_nvec{nvec_def}", lambda: api.defpcg(S, b_dev, z(), W, M, eps=args.eps),
-          lambda: api.defpcg(S, b_dev, z(), W, M, maxit=3, eps=args.eps), 3, bytes_iter + vec_bytes(nvec_def))
+    try:
+        from scipy.linalg import eigh as host_eigh
+        eye = torch.eye(n_Î“, dtype=torch.float64, device="cuda")
+        Sd = torch.stack([S.apply(eye[k].contiguous()) for k in range(n_Î“)], dim=1)
+        ctx.synchronize()
+        Sh = Sd.cpu().numpy()
+        del Sd, eye
+        Wh = host_eigh((Sh + Sh.T) / 2, subset_by_index=[0, nvec_def - 1])[1]
+        W = torch.from_numpy(np.ascontiguousarray(Wh.T)).cuda().T                  # n x nvec, column-major
+        entry(f"defpcg_nvec{nvec_def}", lambda: api.defpcg(S, b_dev, z(), W, M, eps=args.eps),
+              lambda: api.defpcg(S, b_dev, z(), W, M, maxit=3, eps=args.eps), 3, bytes_iter + vec_bytes(nvec_def))
+    except Exception as e:   # noqa: BLE001
+        out[f"defpcg_nvec{nvec_def}"] = {"error": f"{type(e).__name__}: {e}"}
     nvec, spdim = int(1.25 * ndom), 3 * ndom
     entry(f"eigpcg_nvec{nvec}_spdim{spdim}", lambda: api.eigpcg(S, b_dev, z(), M, nvec, spdim, eps=args.eps),
           lambda: api.eigpcg(S, b_dev, z(), M, nvec, spdim, maxit=3, eps=args.eps), 3, bytes_iter)
-    Wrec = api.eigpcg(S, b_dev, z(), M, nvec, spdim, eps=args.eps)[3]
-    entry(f"eigdefpcg_nvec{nvec}_spdim{spdim}", lambda: api.eigdefpcg(S, b_dev, z(), M, Wrec, spdim, eps=args.eps),
-          lambda: api.eigdefpcg(S, b_dev, z(), M, Wrec, spdim, maxit=3, eps=args.eps), 3, bytes_iter + vec_bytes(nvec) * 2)
+    try:
+        Wrec = api.eigpcg(S, b_dev, z(), M, nvec, spdim, eps=args.eps)[3]
+        entry(f"eigdefpcg_nvec{nvec}_spdim{spdim}", lambda: api.eigdefpcg(S, b_dev, z(), M, Wrec, spdim, eps=args.eps),
+              lambda: api.eigdefpcg(S, b_dev, z(), M, Wrec, spdim, maxit=3, eps=args.eps), 3, bytes_iter + vec_bytes(nvec) * 2)
+    except Exception as e:   # noqa: BLE001
+        out[f"eigdefpcg_nvec{nvec}_spdim{spdim}"] = {"error": f"{type(e).__name__}: {e}"}
     entry("cg_unpreconditioned", lambda: api.cg(S, b_dev, z(), eps=args.eps),
           lambda: api.cg(S, b_dev, z(), maxit=20, eps=args.eps), 20, bytes_iter // 2)
+    try:
+        config2_entry(args, api, fem, ctx, entry, torch)
+    except Exception as e:   # noqa: BLE001
+        out["config2_fullA_jacobi_pcg_250k"] = {"error": f"{type(e).__name__}: {e}"}
+    return many_subdomains_entry(args, api, fem, ctx, entry, torch, out, t_all)
+
+
+def config2_entry(args, api, fem, ctx, entry, torch):
     # ---- config 2: N = 500, full A, Jacobi-PCG (Example01:33-61 with Jacobi for AMG)
     mesh = fem.get_mesh(500)
     d = fem.get_dirichlet_inds(mesh.points, mesh.point_marker)
@@ -191,6 +217,9 @@ def secondary_measurements(args, api, fem, ctx, S, M, b_dev, n_Î“, ndom, bytes_i
           {"workload": f"configs[1]: N=500, n={n}, nnz={A.nnz}, pcg(A,b,0,Jacobi)",
            "spmv_replayed_us": round(us, 3), "spmv_bytes": int(spmv_bytes),
            "spmv_replayed_frac": round(spmv_bytes / us / 1e3 / HBM_PEAK_GBS, 4)})
+
+
+def many_subdomains_entry(args, api, fem, ctx, entry, torch, out, t_all):
     # ---- the reference's own partition sizes (80-500 subdomains, KarhunenLoeveDomainDecompositionHelper.jl:14-32): 160
     # subdomains of an N = 400 mesh, n_Î“ = 9417 > 8192: the generic multi-workgroup loop (tests/test_gpu_manydomains.py)
     if not getattr(args, "many_subdomains", False):
@@ -244,6 +273,129 @@ def setup_measurement(api, ctx, P, S, M):
     return {"plan_once_s": round(t_plan, 3), "assemble_local_schurs_ms": round(t_S * 1e3, 1), "pinv_ms": round(t_pinv * 1e3, 1),
             "set_blocks_ms": round(t_set * 1e3, 2), "max_rel_diff_vs_host_blocks": err,
             "note": "S_d: block Gauss-Jordan level elimination (fp64 MFMA), all subdomains batched, one hipGraph replay; look-ahead pivots; pinv: the same inversion for blocks whose norm certificate shows full rank, rocSOLVER dsyevd otherwise"}
+
+
+def config5_measurement(args, api, fem, ctx, mesh, P, f, uex, nreals=50, check_first=3):
+    """BASELINE.json configs[4] end to end on ONE GPU (it is "replicas only": every GPU of a node runs this same chain on
+    its own realizations): `nreals` consecutive realizations of the lognormal coefficient, each ENTIRELY on the device â€”
+    coefficient a = exp(Î¨ (âˆšÎ› Î¾_t)) -> element loop (mi_assembly_run; `prepare_local_schurs`, Example07:162-171) -> S_d and
+    the condensed right-hand side (mi_schur_setup_run; Example07:180-187, EPDD.jl:667-695, 853-861) -> operator refill
+    (mi_dense_set_blocks) -> b_schur -> the recycling pair of Example09_..._Functions.jl:345,364 with the Î¾ = 0
+    preconditioner Î Snn_0 fixed (Example07:152-154, 273): `eigpcg` for the first system, `eigdefpcg` with the W the previous
+    solve returned for every later one (nvec = 1.25 ndom, spdim = 3 ndom, Example09:39-40). Reports realizations/s, the time
+    split, the histogram of `it`; for the first `check_first` realizations `it` is ASSERTED against the C / numpy oracle on
+    the same blocks, right-hand side and incoming W (rank 0, outside the timed figure)."""
+    import torch
+    # torch kernels (coefficient, b_schur) and the library's launches interleave: one stream for both â€” a torch stream of
+    # its own, not the legacy default stream (the solvers capture graphs)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx.use_torch_stream()
+        try:
+            return _config5_chain(args, api, fem, ctx, mesh, P, f, uex, nreals, check_first)
+        finally:
+            ctx.synchronize()
+            ctx.use_own_stream()
+
+
+def _config5_chain(args, api, fem, ctx, mesh, P, f, uex, nreals, check_first):
+    import torch
+    sub = P.sub
+    n, ndom = sub.n_Î“, sub.ndom
+    t_once = time.perf_counter()
+    plan = fem.make_assembly_plan(mesh.cells, mesh.points, P.epart, sub, f, uex)
+    dev_plan = api.AssemblyPlan(ctx, plan)
+    setup = api.SchurSetup(ctx, P.A_IIdd, P.A_IÎ“dd, P.A_Î“Î“dd)
+    kl = fem.synthetic_kl(mesh.points)
+    Psi = torch.from_numpy(kl.Î¨).cuda()
+    sqrtL = np.sqrt(kl.Î›)
+    gidx = [torch.from_numpy(np.asarray(g, dtype=np.int64)).cuda() for g in sub.gather_idx]
+
+    def realize(a_dev):   # everything of a realization's set-up on the stream; returns (S_d blocks on the device, b_schur)
+        vals = dev_plan.run(a_dev)
+        ii, ig, gg, bI, bÎ“ = dev_plan.block_values(vals)
+        Sd, w = setup.run(ii, ig, gg, bI)
+        b = bÎ“.clone()
+        off = 0
+        for d in range(ndom):                      # get_schur_rhs, EPDD.jl:853-861: subdomains in ascending order
+            b[gidx[d]] -= w[off:off + sub.n_Î“d[d]]
+            off += sub.n_Î“d[d]
+        return Sd, b
+
+    # Î¾ = 0: the reference operator and its Neumann-Neumann preconditioner, built once (Example07:88-154)
+    Sd0, _ = realize(torch.ones(plan.n_node, dtype=torch.float64, device="cuda"))
+    S5 = api.LocalSchurs(ctx, P.Sd, sub.gather_idx, sub.node_Î“_cnt)
+    M0 = api.NeumannNeumannSchurPreconditioner(ctx, P.Î Sd, sub.gather_idx, sub.node_Î“_cnt)
+    Pi0 = api.nn_pinv(ctx, sub.n_Î“d, Sd0)
+    M0.set_blocks(Pi0)
+    ctx.synchronize()
+    t_once = time.perf_counter() - t_once
+    rng = np.random.default_rng(args.seed)
+    xis = [rng.standard_normal(kl.Î›.size) for _ in range(nreals)]    # consecutive draws of the same generator
+    nvec, spdim = int(1.25 * ndom), 3 * ndom
+    its, split = [], {"coefficient_and_assembly": 0.0, "assemble_local_schurs_and_rhs": 0.0, "set_blocks": 0.0, "solve": 0.0}
+    checks = []
+    W = None
+    x0 = torch.zeros(n, dtype=torch.float64, device="cuda")
+
+    def lap(key, t):
+        ctx.synchronize(); torch.cuda.synchronize()
+        now = time.perf_counter()
+        split[key] += now - t
+        return now
+
+    # warm-up realization (graphs, work space), not counted
+    Sdw, bw = realize(torch.exp(Psi @ torch.from_numpy(sqrtL * xis[0]).cuda()))
+    S5.set_blocks(Sdw)
+    api.eigpcg(S5, bw, x0.clone(), M0, nvec, spdim)
+    ctx.synchronize(); torch.cuda.synchronize()
+    t_all = time.perf_counter()
+    for t in range(nreals):
+        t0 = time.perf_counter()
+        a = torch.exp(Psi @ torch.from_numpy(sqrtL * xis[t]).cuda())
+        vals = dev_plan.run(a)
+        ii, ig, gg, bI, bÎ“ = dev_plan.block_values(vals)
+        t0 = lap("coefficient_and_assembly", t0)
+        Sd, w = setup.run(ii, ig, gg, bI)
+        b = bÎ“.clone()
+        off = 0
+        for d in range(ndom):
+            b[gidx[d]] -= w[off:off + sub.n_Î“d[d]]
+            off += sub.n_Î“d[d]
+        t0 = lap("assemble_local_schurs_and_rhs", t0)
+        S5.set_blocks(Sd)
+        t0 = lap("set_blocks", t0)
+        W_in = W
+        if W is None:
+            x, it, res, W = api.eigpcg(S5, b, x0.clone(), M0, nvec, spdim)
+        else:
+            x, it, res, W = api.eigdefpcg(S5, b, x0.clone(), M0, W, spdim)
+        t0 = lap("solve", t0)
+        its.append(int(it))
+        if t < check_first:      # inputs of this solve, for the oracle check after the timed loop
+            to_host = lambda v: v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)   # noqa: E731
+            checks.append(([np.asfortranarray(to_host(blk)) for blk in setup.blocks(Sd)], to_host(b),
+                           None if W_in is None else np.asfortranarray(to_host(W_in)), int(it)))
+            t_all += time.perf_counter() - t0     # (the copies for the check are not part of the chain)
+    elapsed = time.perf_counter() - t_all
+    out = {"realizations": nreals, "realizations_per_s": round(nreals / elapsed, 3), "ms_per_realization": round(elapsed / nreals * 1e3, 1),
+           "split_ms_per_realization": {k: round(v / nreals * 1e3, 2) for k, v in split.items()},
+           "it_histogram": {str(k): int(v) for k, v in sorted(zip(*np.unique(its, return_counts=True)))},
+           "it_first": its[:8], "nvec": nvec, "spdim": spdim, "once_s": round(t_once, 2),
+           "chain": "a=exp(Î¨âˆšÎ›Î¾_t) -> mi_assembly_run -> mi_schur_setup_run -> mi_dense_set_blocks -> eigpcg (t=0) / eigdefpcg(W recycled), Î Snn_0 fixed; "
+                    "one GPU (config 5 is replicas only: N GPUs run N such chains)"}
+    if not args.no_cpu_baseline and checks:
+        from oracle import oracle as orc
+        Pi0_h = [np.asfortranarray(blk.cpu().numpy()) for blk in setup.blocks(Pi0)]
+        Mo = orc.neumann_neumann_operator(Pi0_h, sub.gather_idx, sub.node_Î“_cnt)
+        ito = []
+        for blocks, bh, Wh, it_dev in checks:
+            So = orc.apply_local_schurs_operator(blocks, sub.gather_idx, n)
+            r = orc.eigpcg(So, bh, np.zeros(n), Mo, nvec, spdim) if Wh is None else orc.eigdefpcg(So, bh, np.zeros(n), Mo, np.asfortranarray(Wh), spdim)
+            ito.append(int(r[1]))
+            assert r[1] == it_dev, f"config 5: device it={it_dev}, oracle it={r[1]}"
+        out["it_oracle_first"] = ito
+    return out
 
 
 class StdoutToStderr:
@@ -312,12 +464,15 @@ def main():
     ap.add_argument("--kernel-reps", type=int, default=200)
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, RCCL communicator, all-reduces) even with one rank")
+    ap.add_argument("--exchange", choices=["auto", "peer", "rccl"], default="auto",
+                    help="multi-GPU Î“-sum: the one-shot peer exchange when every rank can map its peers' arenas (auto), or RCCL all-reduces")
     ap.add_argument("--shard-precond", action="store_true",
                     help="multi-GPU: shard the Neumann-Neumann blocks like S (two all-reduces per iteration) instead of replicating them")
     ap.add_argument("--workload", choices=["schur", "fullA"], default="schur",
                     help="schur: configs[2] (headline, default). fullA: configs[1], pcg on the full matrix (CSR SpMV + BLAS-1)")
     ap.add_argument("--eps", type=float, default=1e-7, help="stop tolerance (reference constant 1e-7; other values for analysis only)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (deflated / recycling loops, config 2)")
+    ap.add_argument("--config5-reals", type=int, default=50, help="realizations of the config-5 chain in `secondary.config5`")
     ap.add_argument("--many-subdomains", action="store_true",
                     help="add the 160-subdomain problem (n_Î“ = 9417) to `secondary`; off by default so that the kernel statistics of the "
                          "default command contain the headline's launches of k_gemv_pcg only")
@@ -342,6 +497,7 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_dist
+    peer_on = False
     if multi:
         if "RANK" not in os.environ:      # --force-dist from a plain `python bench.py`: a one-rank rendezvous on the loopback
             import socket
@@ -379,6 +535,38 @@ def main():
             uid = torch.frombuffer(bytearray(ctx.unique_id()), dtype=torch.uint8).cuda()
         dist.broadcast(uid, 0)
         ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        # The one-shot peer exchange (include/mi355schur.h) carries the tables of the folded launches when every rank can
+        # map every other rank's arena (same node, peer access over xGMI): IPC handles travel through torch.distributed.
+        # All ranks take the same decision; otherwise RCCL carries everything.
+        if args.exchange != "rccl":
+            ok, handle = 1, None
+            try:
+                ctx.peer_init(rank, world)
+                handle, _ = ctx.peer_export()
+            except Exception as e:                               # noqa: BLE001
+                ok = 0
+                log(rank, f"peer exchange unavailable on rank {rank}: {e}")
+            handles = [None] * world
+            dist.all_gather_object(handles, handle)
+            if ok and all(h is not None for h in handles):
+                try:
+                    for q, h in enumerate(handles):
+                        if q != rank:
+                            ctx.peer_import(q, h)
+                except Exception as e:                           # noqa: BLE001
+                    ok = 0
+                    log(rank, f"peer exchange: cannot map a peer's arena from rank {rank}: {e}")
+            else:
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            peer_on = bool(flag.item())
+            if peer_on:
+                ctx.peer_ready()
+            elif args.exchange == "peer":
+                raise SystemExit("--exchange peer: the peer exchange could not be set up on every rank")
+        if peer_on and world > 1:
+            args.shard_precond = True      # both operators sharded: two cheap exchanges per iteration instead of a replicated Î S stream
         bs = torch.from_numpy(P.b_schur).cuda()
         dist.all_reduce(bs)                                     # b_schur = Î£_ranks (set-up plumbing)
         b_host = bs.cpu().numpy()
@@ -462,7 +650,7 @@ def main():
         return float(np.median(ts))
 
     short = max(2, min(5, its - 2))
-    folded = (not multi or not args.shard_precond) and its > short + 2   # S sharded + NN replicated also runs the folded loop
+    folded = (not multi or not args.shard_precond or peer_on) and its > short + 2   # sharded S (and, with the peer exchange, sharded NN blocks) also run the folded loop
     k_us = None
     if folded:
         t_short = gpu_ms(short)
@@ -506,7 +694,14 @@ def main():
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary:
         secondary = secondary_measurements(args, api, fem, ctx, S, M, b_dev, n_Î“, ndom, bytes_dom + bytes_nn, e0, e1)
-        secondary["device_setup_per_realization"] = setup_measurement(api, ctx, P, S, M)
+        try:
+            secondary["device_setup_per_realization"] = setup_measurement(api, ctx, P, S, M)
+        except Exception as e:   # noqa: BLE001
+            secondary["device_setup_per_realization"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            secondary["config5"] = config5_measurement(args, api, fem, ctx, mesh, P, f, uex, nreals=args.config5_reals)
+        except Exception as e:   # noqa: BLE001
+            secondary["config5"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---------------- CPU baseline: the oracle (C restatement) on this box's host cores, rank 0, N=1 only
     cpu = None
@@ -541,8 +736,12 @@ def main():
                        "subdomains_per_gpu": hi - lo,
                        "parallelism": ("single GPU" if not multi else
                                        f"S sharded {hi - lo} subdomain(s)/GPU; NN blocks "
-                                       + ("sharded: 4-launch loop, 2 RCCL all-reduces of the slot tables per iteration" if args.shard_precond
-                                          else "replicated: folded loop, 1 RCCL all-reduce of the S launch's contribution table per iteration")),
+                                       + ("sharded: folded loop, one peer exchange (xGMI peer stores + flags, csrc/exchange.hpp) behind each of the two launches"
+                                          if args.shard_precond and peer_on else
+                                          "sharded: 4-launch loop, 2 RCCL all-reduces of the slot tables per iteration" if args.shard_precond
+                                          else "replicated: folded loop, 1 exchange of the S launch's contribution table per iteration ("
+                                               + ("peer stores" if peer_on else "RCCL all-reduce") + ")")),
+                       "exchange": ("peer" if peer_on else "rccl") if multi else None,
                        "it": its, "loop_iterations_per_solve": loop_its,
                        "final_relres": relres, "launches_per_iteration": 2 if folded else 4},
             "roofline": roofline,

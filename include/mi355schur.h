@@ -105,6 +105,8 @@ int mi_ctx_set_exchange(mi_ctx_t ctx, int use_peer_exchange);
 #define MI_QUERY_PEER_EXCHANGE 1
 #define MI_QUERY_GRAPH_REPLAYS 2
 #define MI_QUERY_EXCHANGES 3
+#define MI_QUERY_EXPERIMENTAL 5    /* 1: built with `make EXPERIMENTAL=1` (persistent on-chip PCG, rocBLAS/rocSOLVER set-up route) */
+#define MI_QUERY_SPECTRAL_PINV 4   /* blocks of mi_nn_pinv that went to the eigen-decomposition (rocSOLVER) so far, process-wide */
 int mi_ctx_query(mi_ctx_t ctx, int what, int64_t *out);
 /* Test facility: in-process ranks. `n_ranks` contexts of ONE process (one host thread each, typically all on the same
  * device) call mi_ctx_loopback_init with the same group and then behave like ranks of a multi-GPU job: operators built
@@ -287,16 +289,26 @@ int mi_schur_matfree_interior_solutions(mi_op_t op, const double *u_gamma, const
  * S_d = A_ΓΓdd - A_IΓdd' A_IIdd^{-1} A_IΓdd of ALL subdomains, symmetrised from the upper triangle as the reference does
  * (`Symmetric(Array(...))`, :692), and — optionally — the condensed right-hand sides w_d = A_IΓdd' (A_IIdd \ b_Id) that
  * `get_schur_rhs` subtracts from b_Γ (EPDD.jl:853-861). The reference applies apply_local_schur (interior CG, reltol 1e-9) to
- * every unit vector; here the interior is eliminated exactly, level by level (block-tridiagonal Cholesky over breadth-first
- * levels grown from Γ_d; rocBLAS / rocSOLVER for the dense steps) — a documented deviation that only tightens S_d.
+ * every unit vector; here the interior is eliminated exactly, level by level over breadth-first levels grown from Γ_d, with
+ * hand-written kernels: Z_k = T_k^{-1} by block Gauss-Jordan WITHOUT pivoting on the fp64 matrix cores (csrc/setup_gj.hpp;
+ * every T_k is SPD), one hipGraph replay per realization — a documented deviation that only tightens S_d (measured against
+ * the reference's semantics: tests/test_gpu_setup.py::test_device_setup_against_the_reference_semantics). Break-down: an
+ * interior block that is singular or not positive definite (the reference's CHOLMOD paths would throw PosDefException)
+ * shows as Inf / NaN in S_d: host-pointer mode returns MI_ERR_SINGULAR from run; device-pointer mode is asynchronous and
+ * the next mi_nn_pinv on such blocks returns MI_ERR_SINGULAR. (MI355_SETUP_LIB=1 in an EXPERIMENTAL build selects a
+ * rocBLAS / rocSOLVER block-Cholesky route instead; there potrf's info is what host-pointer mode reports.)
  *   create: the sparsity of the blocks (CSC colptr / rowval as for mi_schur_matfree_device_create), once per mesh / partition
  *   run   : one realization. ii_val / ig_val / gg_val: the concatenations over the subdomains of the blocks' CSC nzval arrays
  *           (the layout mi_assembly_run produces and mi_schur_matfree_set_values takes); b_I: concatenated b_Id or NULL.
  *           Sd receives the concatenated column-major n_Γd x n_Γd blocks, w (may be NULL) the concatenated w_d. Host or
  *           device pointers per the context's pointer mode; with device pointers the call is asynchronous on the stream.
  * mi_nn_pinv — `prepare_neumann_neumann_schur_precond(Sd, ...)` (EPDD.jl:1201-1220): ΠS_d = pinv(S_d, rtol) of the symmetric
- * blocks through their eigen-decomposition (singular values = |eigenvalues|; those <= rtol * the largest are dropped, as
- * LinearAlgebra.pinv does); rtol <= 0 means sqrt(eps(Float64)), the reference's value.
+ * blocks; rtol <= 0 means sqrt(eps(Float64)), the reference's value. LinearAlgebra.pinv drops the singular values
+ * <= rtol * the largest. Three routes, tried in this order per block, all giving that result: (1) 1/||S^{-1}||_inf >
+ * rtol ||S||_inf proves that nothing is dropped: the pseudo-inverse is the inverse (the Gauss-Jordan kernels of the set-up);
+ * (2) floating subdomains, ||S 1||_inf <= rtol ||S||_inf: S^+ = (S + α u u')^{-1} - u u'/α, u = 1/sqrt(n), α = ||S||_inf, the
+ * same kernels and the same certificate on the shifted matrix; (3) anything else (rank deficiency > 1): eigen-decomposition
+ * (rocSOLVER dsyevd, bound with dlopen; singular values = |eigenvalues|). MI_QUERY_SPECTRAL_PINV counts route (3).
  * mi_dense_set_blocks — new blocks (concatenated, column-major) for an existing mi_schur_assembled / mi_nn operator on the same
  * maps: the per-realization update of S (Example07:180-199) without re-creating the operator. */
 typedef struct mi_setup_s *mi_setup_t;

@@ -107,9 +107,31 @@ class Context:
         check(self._L.mi_ctx_set_chunk(self._h, C.c_int(iterations_per_graph)))
 
     def use_torch_stream(self) -> None:
-        """Launch on torch's current stream (so torch.cuda.Event sees our kernels)."""
+        """Launch on torch's current stream (so torch.cuda.Event sees our kernels, and tensors produced by torch kernels
+        just before a call are ordered with it). Not the legacy default stream: the solvers capture graphs."""
         import torch
         check(self._L.mi_ctx_set_stream(self._h, vp(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def use_own_stream(self) -> None:
+        check(self._L.mi_ctx_set_stream(self._h, None))
+
+    def _record(self, *tensors) -> None:
+        """Asynchronous entry points (`mi_dense_set_blocks`, `mi_schur_setup_run`, `mi_nn_pinv`, `mi_assembly_run` in
+        device-pointer mode) return while the context's stream still reads / writes the caller's torch tensors. Tell
+        torch's caching allocator: a tensor that dies right after the call is not handed out again before the stream has
+        passed this point (contract: INTEGRATION.md "device pointers"; the ORDER between torch's stream and the
+        context's stream is the caller's: `use_torch_stream()` or a synchronisation)."""
+        ts = [t for t in tensors if t is not None and _is_torch(t) and t.is_cuda]
+        if not ts:
+            return
+        import torch
+        sp = vp()
+        check(self._L.mi_ctx_get_stream(self._h, C.byref(sp)))
+        if not sp.value:
+            return
+        ext = torch.cuda.ExternalStream(sp.value, device=ts[0].device)
+        for t in ts:
+            t.record_stream(ext)
 
     def synchronize(self) -> None:
         check(self._L.mi_ctx_synchronize(self._h))
@@ -148,9 +170,9 @@ class Context:
         check(self._L.mi_ctx_set_exchange(self._h, C.c_int(1 if use_peer_exchange else 0)))
 
     def query(self, what: str) -> int:
-        """`mi_ctx_query`: "no_graph", "peer_exchange", "graph_replays", "exchanges"."""
+        """`mi_ctx_query`: "no_graph", "peer_exchange", "graph_replays", "exchanges", "spectral_pinv"."""
         out = i64(0)
-        check(self._L.mi_ctx_query(self._h, C.c_int({"no_graph": 0, "peer_exchange": 1, "graph_replays": 2, "exchanges": 3}[what]), C.byref(out)))
+        check(self._L.mi_ctx_query(self._h, C.c_int({"no_graph": 0, "peer_exchange": 1, "graph_replays": 2, "exchanges": 3, "spectral_pinv": 4, "experimental": 5}[what]), C.byref(out)))
         return int(out.value)
 
     def peer_connect(self, rank: int, n_ranks: int, all_gather) -> None:
@@ -586,6 +608,7 @@ class AssemblyPlan:
             out = np.empty(self.plan.n_entries)
             po = vp(out.ctypes.data)
         check(self.ctx._L.mi_assembly_run(self._h, pa, po))
+        self.ctx._record(a_nodal, out)
         return out
 
     def block_values(self, values, lo: int = 0, hi: Optional[int] = None):
@@ -655,6 +678,7 @@ class SchurSetup:
             w = np.empty(self.n_w) if b_I is not None else None
             pS, pw = vp(Sd.ctypes.data), (vp(w.ctypes.data) if w is not None else None)
         check(self.ctx._L.mi_schur_setup_run(self._h, p1, p2, p3, p4, pS, pw))
+        self.ctx._record(ii_val, ig_val, gg_val, b_I, Sd, w)
         return Sd, w
 
     def blocks(self, Sd):
@@ -692,6 +716,7 @@ def nn_pinv(ctx: Context, n_Γd, Sd, rtol: float = 0.0):
         out = np.empty(k.size)
         po = vp(out.ctypes.data)
     check(ctx._L.mi_nn_pinv(ctx._h, i64(nd.size), nd.ctypes.data_as(i64p), p, C.c_double(rtol), po))
+    ctx._record(Sd, out)
     return out
 
 
@@ -700,6 +725,7 @@ def _set_blocks(self, blocks):
     self.ctx._mode_for(blocks)
     k, p = self.ctx._ptr(blocks)
     check(self.ctx._L.mi_dense_set_blocks(self._h, p))
+    self.ctx._record(blocks)
 
 
 LocalSchurs.set_blocks = _set_blocks

@@ -432,6 +432,14 @@ int mi_ctx_query(mi_ctx_t ctx, int what, int64_t *out) {
       case MI_QUERY_NO_GRAPH: *out = ctx->no_graph ? 1 : 0; break;
       case MI_QUERY_PEER_EXCHANGE: *out = ctx->use_peer() ? (ctx->peer->fine_grained ? 2 : 1) : 0; break;
       case MI_QUERY_GRAPH_REPLAYS: *out = ctx->n_replays; break;
+      case MI_QUERY_SPECTRAL_PINV: *out = spectral_pinv_calls().load(); break;
+      case MI_QUERY_EXPERIMENTAL:
+#ifdef MI355_EXPERIMENTAL
+        *out = 1;
+#else
+        *out = 0;
+#endif
+        break;
       case MI_QUERY_EXCHANGES: {
         unsigned long long e = 0;
         if (ctx->peer) {
@@ -953,11 +961,19 @@ int mi_schur_setup_run(mi_setup_t plan, const double *ii_val, const double *ig_v
     In a(c, ii_val, (size_t)plan->n_ii, plan->st_ii), b(c, ig_val, (size_t)plan->n_ig, plan->st_ig), g(c, gg_val, (size_t)plan->n_gg, plan->st_gg),
         bi(c, b_I, b_I ? (size_t)plan->n_bi : 0, plan->st_bi);
     InOut so(c, Sd, (size_t)plan->n_s, plan->st_S, false), wo(c, w, w ? (size_t)plan->n_w : 0, plan->st_w, false);
-    if (plan->lanes.empty()) gj_run(*plan, a.dev, b.dev, g.dev, b_I ? bi.dev : nullptr, so.dev, w ? wo.dev : nullptr);
-    else setup_plan_run(*plan, a.dev, b.dev, g.dev, b_I ? bi.dev : nullptr, so.dev, w ? wo.dev : nullptr);   // MI355_SETUP_LIB=1
+#ifdef MI355_EXPERIMENTAL
+    if (!plan->lanes.empty()) setup_plan_run(*plan, a.dev, b.dev, g.dev, b_I ? bi.dev : nullptr, so.dev, w ? wo.dev : nullptr);   // MI355_SETUP_LIB=1
+    else
+#endif
+    gj_run(*plan, a.dev, b.dev, g.dev, b_I ? bi.dev : nullptr, so.dev, w ? wo.dev : nullptr);
     so.finish();
     wo.finish();
-    if (c->ptr_mode != MI_PTR_DEVICE) {   // host mode is synchronous: a Cholesky that met a non-positive pivot is reported
+    if (c->ptr_mode != MI_PTR_DEVICE) {   // host mode is synchronous: a break-down is reported
+      // Gauss-Jordan route (the default): no pivoting, so an interior block that is not positive definite shows as Inf / NaN
+      // in S_d (the reference's CHOLMOD would throw PosDefException). Device-pointer mode stays asynchronous: there the
+      // next mi_nn_pinv reports non-finite blocks.
+      for (size_t i = 0; i < (size_t)plan->n_s; ++i)
+        if (!std::isfinite(Sd[i])) return fail(MI_ERR_SINGULAR, "mi_schur_setup_run: S_d is not finite (an interior block is singular or not positive definite)");
       for (auto &l : plan->lanes) {
         int info[2] = {0, 0};
         memcpy_sync(info, l.info.p, sizeof info, hipMemcpyDeviceToHost);
@@ -971,7 +987,7 @@ int mi_schur_setup_destroy(mi_setup_t plan) {
   if (!plan) return MI_OK;
   return guarded([&]() -> int {
     plan->ctx->use();
-    (void)hipDeviceSynchronize();
+    (void)hipStreamSynchronize(plan->ctx->stream);
     delete plan;
     return MI_OK;
   });

@@ -279,7 +279,10 @@ inline void setup_plan_build(mi_setup_s &P, mi_ctx_s *c, int64_t ndom, const int
   hipStream_t s = c->stream;
   P.src.upload(src, s); P.dst.upload(dst, s); P.perm.upload(perm_all, s);
   P.c_ptr.upload(P.c_ptr_h, s); P.c_row.upload(P.c_row_h, s); P.c_src.upload(P.c_src_h, s);
-  if (!env_int("MI355_SETUP_LIB", 0)) return;   // the library path (rocBLAS / rocSOLVER chains) is the cross-check, on request
+#ifndef MI355_EXPERIMENTAL
+  return;                                       // the library path (rocBLAS / rocSOLVER chains) exists in EXPERIMENTAL builds only
+#else
+  if (!env_int("MI355_SETUP_LIB", 0)) return;   // ... and there on request (`make EXPERIMENTAL=1`, MI355_SETUP_LIB=1)
   RocLa &la = RocLa::get();
   // One chain at a time by default: with several rocSOLVER/rocBLAS handles running potrf / trsm chains concurrently on
   // different streams some S_d came out wrong at the 1e-7 level (tools/setup_probe.py, config 3), with one stream every
@@ -296,8 +299,10 @@ inline void setup_plan_build(mi_setup_s &P, mi_ctx_s *c, int64_t ndom, const int
     MI_HIP(hipMemsetAsync(l.info.p, 0, 2 * sizeof(int), s));
   }
   MI_HIP(hipStreamSynchronize(s));
+#endif
 }
 
+#ifdef MI355_EXPERIMENTAL
 // One realization: values (device pointers; the concatenations over subdomains of the CSC nzval arrays and of b_Id) ->
 // Sd (concatenated column-major blocks) and, with bI != nullptr, w (concatenated). Enqueued on the plan's streams, which
 // first wait for the context's stream and are joined back into it at the end.
@@ -375,6 +380,7 @@ inline void setup_plan_run(mi_setup_s &P, const double *ii_val, const double *ig
   }
   (void)hipEventDestroy(ev0);
 }
+#endif   // MI355_EXPERIMENTAL
 
 // ΠS_d = pinv(S_d, rtol) for the concatenated symmetric blocks (device pointers): S = V diag(lam) V', singular values |lam|.
 inline void pinv_blocks(mi_ctx_s *c, int ndom, const int64_t *n_gamma_d, const double *Sd, double rtol, double *Pi) {

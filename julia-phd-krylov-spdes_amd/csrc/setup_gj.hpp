@@ -17,6 +17,8 @@
 // All subdomains advance together (grid.z), aligned so that they reach level 0 in the same step. The launch sequence
 // depends only on the plan: it is captured once and replayed per realization on plan-owned buffers.
 #pragma once
+#include <atomic>
+
 #include "setup_dense.hpp"
 
 namespace mi {
@@ -524,74 +526,128 @@ inline void gj_run(mi_setup_s &P, const double *ii_val, const double *ig_val, co
 // `pinv(S_d, rtol)` keeps the singular values above rtol * σ_max. If 1 / ||S^{-1}||_inf > rtol * ||S||_inf then
 // σ_min >= 1 / ||S^{-1}||_2 >= 1 / ||S^{-1}||_inf > rtol ||S||_inf >= rtol σ_max: nothing is dropped and the pseudo-inverse IS the
 // inverse — computed by the block Gauss-Jordan kernels above in ~1 ms instead of an eigen-decomposition (~30 ms per block
-// through rocSOLVER). Blocks that fail the test (floating subdomains: S_d 1 = 0) keep the spectral route.
-__global__ __launch_bounds__(256) void k_rowsum_max(int n, const double *__restrict__ A, double *__restrict__ out) {
+// through rocSOLVER).
+// FLOATING subdomains (no Dirichlet node: pure Neumann problem, `S_d 1 = 0` — at the reference's own partitions, 80-500
+// subdomains, almost every block) fail that test by construction. For a symmetric positive semi-definite S whose kernel is
+// span{u}, u = 1/sqrt(n):   S^+ = (S + α u u')^{-1} - (1/α) u u'   for any α > 0 (S + α u u' has the eigenpairs of S with
+// the zero eigenvalue replaced by α). With α = ||S||_inf the shifted matrix is as well conditioned as S on its range, the
+// SAME kernels invert it, and the same certificate on it shows that no OTHER singular value lies below the cut-off. Taken
+// when ||S 1||_inf <= rtol ||S||_inf (the constant vector is in the numerical kernel pinv would drop). Only blocks that fail
+// both tests (rank deficiency > 1, or a kernel that is not the constants) go to the spectral route (rocSOLVER dsyevd).
+template <bool SIGNED>
+__global__ __launch_bounds__(256) void k_rowsum_max_t(int n, const double *__restrict__ A, double *__restrict__ out) {
   __shared__ double sm[NT / 64 + 1];
   double m = 0.0;
   for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
     double s2 = 0.0;
-    for (int c = 0; c < n; ++c) s2 += fabs(A[r + (size_t)c * n]);     // symmetric: column sums = row sums, coalesced this way
+    for (int c = 0; c < n; ++c) s2 += SIGNED ? A[r + (size_t)c * n] : fabs(A[r + (size_t)c * n]);   // symmetric: column sums = row sums, coalesced this way
+    s2 = fabs(s2);
     m = fmax(m, isfinite(s2) ? s2 : INFINITY);
   }
-  // max over the workgroup through the deterministic sum helper's scratch: a max tree on wave level, then lanes 0
   for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) out[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
+__global__ __launch_bounds__(256) void k_add_const(long long n, double *__restrict__ A, double c) {
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < n; e += (long long)gridDim.x * 256) A[e] += c;
+}
+// dst = src + c (element-wise)
+__global__ __launch_bounds__(256) void k_copy_add_const(long long n, const double *__restrict__ src, double *__restrict__ dst, double c) {
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < n; e += (long long)gridDim.x * 256) dst[e] = src[e] + c;
+}
+inline std::atomic<long long> &spectral_pinv_calls() { static std::atomic<long long> n{0}; return n; }   // blocks sent to the eigen-decomposition (mi_ctx_query)
+
 inline void pinv_blocks_fast(mi_ctx_s *c, int ndom, const int64_t *n_gamma_d, const double *Sd, double rtol, double *Pi) {
   hipStream_t s = c->stream;
-  if (env_int("MI355_PINV_EIG", 0)) { pinv_blocks(c, ndom, n_gamma_d, Sd, rtol, Pi); return; }
-  // one-step batch of the inversion kernels: T = copy of S_d, result in Z[nb & 1]
+  if (env_int("MI355_PINV_EIG", 0)) { spectral_pinv_calls() += ndom; pinv_blocks(c, ndom, n_gamma_d, Sd, rtol, Pi); return; }
   std::vector<GjStep> st(ndom);
   std::vector<GjDom> dm(ndom);
-  size_t tot = 0, nmax = 1;
+  size_t tot = 0;
   std::vector<size_t> oT(ndom), o0(ndom), o1(ndom), oP(ndom), off(ndom);
   size_t run = 0;
-  int nbmax = 0;
   for (int d = 0; d < ndom; ++d) {
     const size_t n = (size_t)n_gamma_d[d], nn = std::max<size_t>(1, n * n);
     off[d] = run; run += n * n;
     auto take = [&](size_t cnt) { const size_t o = tot; tot += (cnt + 31) / 32 * 32; return o; };
     oT[d] = take(nn); o0[d] = take(nn); o1[d] = take(nn); oP[d] = take(2 * GJ_B * GJ_B);
-    nmax = std::max(nmax, n);
   }
-  DevBuf<double> pool(tot + 32), norms((size_t)2 * ndom * 8);
+  DevBuf<double> pool(tot + 32), norms((size_t)3 * ndom * 8);
   for (int d = 0; d < ndom; ++d) {
     const int n = (int)n_gamma_d[d];
     st[d] = GjStep{}; st[d].n0 = n; st[d].nb = (n + GJ_B - 1) / GJ_B;
     dm[d] = GjDom{}; dm[d].T = pool.p + oT[d]; dm[d].Z[0] = pool.p + o0[d]; dm[d].Z[1] = pool.p + o1[d]; dm[d].P = pool.p + oP[d];
-    nbmax = std::max(nbmax, st[d].nb);
-    if (n) MI_HIP(hipMemcpyAsync(dm[d].T, Sd + off[d], sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
   }
-  DevBuf<GjStep> std_; DevBuf<GjDom> dmd;
-  std_.upload(st, s); dmd.upload(dm, s);
   auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
-  for (int kb = 0; kb < nbmax; ++kb) {
-    if (kb == 0) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, ndom), dim3(64), 0, s, 0, kb, ndom, std_.p, dmd.p);   // later pivots: look-ahead in the update
-    hipLaunchKernelGGL(k_gj_update, dim3(cdiv((int)nmax, GJ_T), cdiv((int)nmax, GJ_T), ndom), dim3(256), 0, s, 0, kb, ndom, std_.p, dmd.p);
-  }
+  DevBuf<GjStep> std_; DevBuf<GjDom> dmd;
+  // One batch: T_d = S_d + shift_d (every entry) for the blocks `ds`, inverted together; norms of S_d (abs row sums), of the
+  // inverse, and of S_d 1 (signed row sums) come back to the host.
+  auto batch = [&](const std::vector<int> &ds, const std::vector<double> &shift, std::vector<double> &nS, std::vector<double> &nZ,
+                   std::vector<double> &nS1) {
+    std::vector<GjStep> sb; std::vector<GjDom> db;
+    int nmax = 1, nbmax = 0;
+    for (size_t k = 0; k < ds.size(); ++k) {
+      const int d = ds[k], n = (int)n_gamma_d[d];
+      sb.push_back(st[d]); db.push_back(dm[d]);
+      nmax = std::max(nmax, n); nbmax = std::max(nbmax, st[d].nb);
+      if (n) hipLaunchKernelGGL(k_copy_add_const, dim3(std::min(4096, cdiv(n * n, 256))), dim3(256), 0, s, (long long)n * n, Sd + off[d], dm[d].T, shift[k]);
+    }
+    std_.upload(sb, s); dmd.upload(db, s);
+    const int nb_ = (int)ds.size();
+    for (int kb = 0; kb < nbmax; ++kb) {
+      if (kb == 0) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nb_), dim3(64), 0, s, 0, kb, nb_, std_.p, dmd.p);   // later pivots: look-ahead in the update
+      hipLaunchKernelGGL(k_gj_update, dim3(cdiv(nmax, GJ_T), cdiv(nmax, GJ_T), nb_), dim3(256), 0, s, 0, kb, nb_, std_.p, dmd.p);
+    }
+    for (size_t k = 0; k < ds.size(); ++k) {
+      const int d = ds[k], n = (int)n_gamma_d[d];
+      if (!n) continue;
+      hipLaunchKernelGGL(k_rowsum_max_t<false>, dim3(8), dim3(256), 0, s, n, Sd + off[d], norms.p + (size_t)24 * d);
+      hipLaunchKernelGGL(k_rowsum_max_t<false>, dim3(8), dim3(256), 0, s, n, dm[d].Z[st[d].nb & 1], norms.p + (size_t)24 * d + 8);
+      hipLaunchKernelGGL(k_rowsum_max_t<true>, dim3(8), dim3(256), 0, s, n, Sd + off[d], norms.p + (size_t)24 * d + 16);
+    }
+    MI_HIP(hipGetLastError());
+    std::vector<double> nh((size_t)24 * ndom);
+    MI_HIP(hipMemcpyAsync(nh.data(), norms.p, sizeof(double) * nh.size(), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    nS.assign(ndom, 0.0); nZ.assign(ndom, 0.0); nS1.assign(ndom, 0.0);
+    for (int d : ds)
+      for (int k = 0; k < 8; ++k) {
+        nS[d] = std::max(nS[d], nh[(size_t)24 * d + k]); nZ[d] = std::max(nZ[d], nh[(size_t)24 * d + 8 + k]);
+        nS1[d] = std::max(nS1[d], nh[(size_t)24 * d + 16 + k]);
+      }
+  };
+  std::vector<int> all;
+  for (int d = 0; d < ndom; ++d) all.push_back(d);
+  std::vector<double> nS, nZ, nS1, zero(ndom, 0.0);
+  batch(all, zero, nS, nZ, nS1);
+  std::vector<int> floating, slow;
+  std::vector<double> shift;
   for (int d = 0; d < ndom; ++d) {
     const int n = (int)n_gamma_d[d];
     if (!n) continue;
-    hipLaunchKernelGGL(k_rowsum_max, dim3(8), dim3(256), 0, s, n, Sd + off[d], norms.p + (size_t)16 * d);
-    hipLaunchKernelGGL(k_rowsum_max, dim3(8), dim3(256), 0, s, n, dm[d].Z[st[d].nb & 1], norms.p + (size_t)16 * d + 8);
-  }
-  MI_HIP(hipGetLastError());
-  std::vector<double> nh((size_t)16 * ndom);
-  MI_HIP(hipMemcpyAsync(nh.data(), norms.p, sizeof(double) * nh.size(), hipMemcpyDeviceToHost, s));
-  MI_HIP(hipStreamSynchronize(s));
-  std::vector<int> slow;
-  for (int d = 0; d < ndom; ++d) {
-    const int n = (int)n_gamma_d[d];
-    if (!n) continue;
-    double ns = 0.0, nz = 0.0;
-    for (int k = 0; k < 8; ++k) { ns = std::max(ns, nh[(size_t)16 * d + k]); nz = std::max(nz, nh[(size_t)16 * d + 8 + k]); }
-    const bool inv_ok = std::isfinite(ns) && std::isfinite(nz) && nz > 0.0 && 1.0 / nz > rtol * ns;
+    if (!std::isfinite(nS[d])) raise(MI_ERR_SINGULAR, "mi_nn_pinv: block %d is not finite (mi_schur_setup_run met a singular or indefinite interior block)", d);
+    const bool inv_ok = std::isfinite(nS[d]) && std::isfinite(nZ[d]) && nZ[d] > 0.0 && 1.0 / nZ[d] > rtol * nS[d];
     if (inv_ok) MI_HIP(hipMemcpyAsync(Pi + off[d], dm[d].Z[st[d].nb & 1], sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
-    else slow.push_back(d);
+    else if (std::isfinite(nS[d]) && nS[d] > 0.0 && nS1[d] <= rtol * nS[d] && !env_int("MI355_PINV_NO_SHIFT", 0)) {
+      floating.push_back(d);
+      shift.push_back(nS[d] / n);                  // α u u' with α = ||S||_inf, u = 1/sqrt(n): every entry + α / n
+    } else slow.push_back(d);
   }
-  for (int d : slow) pinv_blocks(c, 1, n_gamma_d + d, Sd + off[d], rtol, Pi + off[d]);
+  if (!floating.empty()) {
+    MI_HIP(hipStreamSynchronize(s));               // the copies out of Z above
+    std::vector<double> nS2, nZ2, nS12;
+    batch(floating, shift, nS2, nZ2, nS12);
+    for (size_t k = 0; k < floating.size(); ++k) {
+      const int d = floating[k], n = (int)n_gamma_d[d];
+      const double alpha = shift[k] * n;
+      const bool ok = std::isfinite(nZ2[d]) && nZ2[d] > 0.0 && 1.0 / nZ2[d] > rtol * nS[d];   // every eigenvalue of S + α u u' above the cut-off
+      if (ok) hipLaunchKernelGGL(k_copy_add_const, dim3(std::min(4096, cdiv(n * n, 256))), dim3(256), 0, s, (long long)n * n,
+                                 (const double *)dm[d].Z[st[d].nb & 1], Pi + off[d], -1.0 / (alpha * n));   // - (1/α) u u'
+      else slow.push_back(d);
+    }
+    MI_HIP(hipGetLastError());
+  }
+  for (int d : slow) { ++spectral_pinv_calls(); pinv_blocks(c, 1, n_gamma_d + d, Sd + off[d], rtol, Pi + off[d]); }
   MI_HIP(hipStreamSynchronize(s));   // the work buffers go out of scope
 }
 

@@ -20,7 +20,9 @@
 
 #include "eig_kernels.hpp"
 #include "operators.hpp"
-#include "resident.hpp"
+#ifdef MI355_EXPERIMENTAL
+#include "resident.hpp"   // persistent on-chip PCG: measured and not adopted (profiles/NOTES.md); `make EXPERIMENTAL=1`
+#endif
 
 namespace mi {
 
@@ -37,6 +39,7 @@ struct GraphKey {
   }
 };
 
+#ifdef MI355_EXPERIMENTAL
 // Host side of the persistent on-chip PCG (resident.hpp): which rows of which subdomain every workgroup owns, how many
 // of them fit into registers / LDS, and the hand-off buffers of the grid barrier.
 struct ResidentPlan {
@@ -119,6 +122,9 @@ struct ResidentPlan {
     epoch += 1u << 20;
   }
 };
+#else
+struct ResidentPlan { bool usable = false; };   // (EXPERIMENTAL builds only)
+#endif
 
 struct SolverWorkspace {
   int64_t n = 0;
@@ -312,10 +318,14 @@ struct Krylov {
   // pcg on one GPU with both operators dense on the same maps: the whole solve as one persistent launch with the blocks
   // held in registers / LDS (resident.hpp), when enough of them fit on the chip. nullptr: not applicable.
   ResidentPlan *resident_plan() {
+#ifndef MI355_EXPERIMENTAL
+    return nullptr;
+#else
     if (!fold || nvec > 0 || eig.tag || ctx->has_comm() || Ad->reduce_over_ranks || !env_int("MI355_RESIDENT", 0) || env_int("MI355_NO_RESIDENT", 0)) return nullptr;
     auto &slot = ws.resident[{A, M}];
     if (!slot) slot.reset(new ResidentPlan(ctx, *Ad, *Md));
     return slot->usable ? slot.get() : nullptr;
+#endif
   }
   PcgFold fold_args(int phase) const {
     PcgFold f{};
@@ -716,6 +726,7 @@ struct Krylov {
       MI_HIP(hipGetLastError());
     };
     bool ran_resident = false;
+#ifdef MI355_EXPERIMENTAL
     if (ResidentPlan *rp = resident_plan()) {
       // One persistent launch for the whole solve. It clears `done` itself only by setting it at the end: an aborted
       // launch (bounded spin expired: the workgroups were not all resident) leaves done = 0 and the loops below take over.
@@ -752,6 +763,7 @@ struct Krylov {
         begin(b_in, x_io, W_in, mx, e, cd);   // x0, b and the state block as they were
       }
     }
+#endif
     if (use_graph) {
       const GraphKey pk{A, M, nvec, 0};
       int &predicted = ws.predicted[pk];

@@ -82,3 +82,33 @@ def test_many_subdomain_schur_pcg_generic_loop(pkg, ctx, orc, many, monkeypatch)
     xt, itt, rest = api.pcg(S, torch.from_numpy(b).cuda(), torch.zeros(n, dtype=torch.float64, device="cuda"), M)
     assert itt == got[1] and np.array_equal(xt.cpu().numpy(), got[0])
     orc.set_threads(prev_threads)
+
+
+def test_pinv_of_floating_subdomains_without_an_eigensolver(pkg, ctx, many):
+    """`prepare_neumann_neumann_schur_precond` (EPDD.jl:1201-1220) at the reference's partition sizes: of the 160 subdomains
+    112 are floating (no Dirichlet node: S_d 1 = 0, rank n - 1). `mi_nn_pinv` takes none of them to the eigen-decomposition
+    (rocSOLVER dsyevd): boundary blocks are inverted, floating ones go through S^+ = (S + α u u')^{-1} - u u'/α. Against
+    numpy's SVD pinv with the reference's rtol = sqrt(eps)."""
+    api = pkg.api
+    P = many
+    nd = P.sub.n_Γd
+    Sd = np.concatenate([np.asarray(S, order="F").ravel(order="F") for S in P.Sd])
+    before = ctx.query("spectral_pinv")
+    Pi = api.nn_pinv(ctx, nd, Sd)
+    assert ctx.query("spectral_pinv") == before, "a block went to the eigen-decomposition"
+    rtol = float(np.sqrt(np.finfo(float).eps))
+    off, n_floating, worst = 0, 0, 0.0
+    for d, n in enumerate(nd):
+        got = Pi[off:off + n * n].reshape(n, n).T
+        off += n * n
+        S = np.asarray(P.Sd[d])
+        floating = np.abs(S.sum(axis=1)).max() <= rtol * np.abs(S).sum(axis=1).max()
+        n_floating += int(floating)
+        if d % 7 and not (floating and d % 3 == 0):
+            continue                                                   # a sample keeps the host SVDs short
+        ref = np.linalg.pinv(S, rcond=rtol)
+        worst = max(worst, np.abs(got - ref).max() / np.abs(ref).max())
+        if floating:
+            assert np.abs(got.sum(axis=1)).max() <= 1e-6 * np.abs(got).max()    # the constants are in the kernel of S^+ too
+    assert n_floating >= 100
+    assert worst <= 1e-7, worst

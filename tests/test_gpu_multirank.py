@@ -158,3 +158,42 @@ def test_peer_exchange_handshake_and_expired_wait(pkg):
     with pytest.raises(Exception, match="expired"):
         c0.allreduce_sum(v0.copy())
     assert time.time() - t0 < 30.0
+
+
+def test_peer_exchange_across_processes(pkg, orc, fem, tmp_path):
+    """The production hand-shake: 2 PROCESSES (one context each, both on this GPU), arenas mapped through HIP IPC handles that
+    travel over torch.distributed (gloo, 127.0.0.1) — tests/peer_ipc_worker.py. Both operators sharded, folded loop, the
+    exchanges inside the iteration graphs; ranks bit-identical, oracle parity, and a plain all-reduce through the arenas."""
+    import socket
+    import subprocess
+    import sys
+    world = 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "peer_ipc_worker.py")
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), port, outs[r]], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    r0, r1 = (np.load(o) for o in outs)
+    assert int(r0["peer"]) >= 1 and int(r0["replays"]) >= 1 and int(r0["exchanges"]) == int(r1["exchanges"])
+    assert np.array_equal(r0["y"], r1["y"]) and np.array_equal(r0["x"], r1["x"]) and np.array_equal(r0["res"], r1["res"])
+    assert int(r0["it"]) == int(r1["it"])
+    assert np.array_equal(r0["v"], np.full(7, 3.0)) and np.array_equal(r1["v"], np.full(7, 3.0))
+    from conftest import f_m1 as f1, lognormal_coeff as lc, u0734 as u0
+    mesh = fem.get_mesh(90)
+    P = fem.build_schur_problem(90, 4, 2, lc(fem, mesh.points, 5), f1, u0)
+    So, Mo = orc_ops(orc, P)
+    n, b = P.sub.n_Γ, P.b_schur
+    assert np.allclose(r0["y"], So * b, rtol=0, atol=1e-13 * np.abs(r0["y"]).max())
+    assert_history((r0["x"], int(r0["it"]), r0["res"]), orc.pcg(So, b, np.zeros(n), Mo))

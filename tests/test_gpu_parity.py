@@ -24,6 +24,7 @@ X_RTOL = 1e-6
 
 
 TIGHT_PREFIX = 20
+EQUAL_IT_UPTO = 50     # `it` must equal the oracle's for every solve of at most this many iterations
 
 
 def assert_history(got, want, apply=None, b=None):
@@ -40,6 +41,8 @@ def assert_history(got, want, apply=None, b=None):
         assert np.allclose(res, reso, rtol=RES_RTOL, atol=RES_FLOOR * reso[0]), np.max(np.abs(res - reso) / reso)
         assert np.linalg.norm(x - xo) <= X_RTOL * np.linalg.norm(xo)
         return
+    if max(it, ito) <= EQUAL_IT_UPTO:                             # solves of up to 50 iterations: `it` EQUAL (north_star)
+        assert it == ito, f"iteration counts differ: {it} vs oracle {ito}"
     assert abs(it - ito) <= max(1, ito // 50), f"iteration counts differ: {it} vs oracle {ito}"
     k, m = TIGHT_PREFIX, min(it, ito)
     assert np.allclose(res[:k], reso[:k], rtol=RES_RTOL, atol=RES_FLOOR * reso[0]), \
@@ -409,8 +412,8 @@ def test_folded_deflated_loop_and_resident_loop(pkg, ctx, orc, fem, toy, ragged,
         Wsing = np.asfortranarray(np.column_stack([W[:, 0], W[:, 1], np.zeros(n)]))      # a zero column: U[3,3] == 0 exactly
         with pytest.raises(api.SingularException):
             api.defpcg(S, b, np.zeros(n), Wsing, M)
-        # persistent on-chip pcg
-        for x0 in (np.zeros(n), np.random.default_rng(1).standard_normal(n)):
+        # persistent on-chip pcg: an EXPERIMENTAL build only (`make EXPERIMENTAL=1`; measured and not adopted, profiles/NOTES.md)
+        for x0 in (np.zeros(n), np.random.default_rng(1).standard_normal(n)) if ctx.query("experimental") else ():
             want = orc.pcg(So, b, x0, Mo)
             monkeypatch.setenv("MI355_RESIDENT", "1")
             res_ = api.pcg(S, b, x0, M)

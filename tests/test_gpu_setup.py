@@ -46,7 +46,11 @@ def test_device_assemble_local_schurs_and_pinv(pkg, ctx, fem, N, px, py, seed):
     assert np.array_equal(Sd1, Sd)
     # pinv(S_d, rtol = sqrt(eps)): against numpy's SVD-based pinv of the same blocks (a floating subdomain — the centre box
     # of a 3x3 partition — has the constant vector in its kernel: one singular value dropped on both sides)
+    n_spectral = ctx.query("spectral_pinv")
     Pi = setup.blocks(api.nn_pinv(ctx, sub.n_Γd, Sd))
+    # no block takes the eigen-decomposition (rocSOLVER): full-rank blocks are inverted, the floating subdomain of the
+    # 3x3 partition goes through the rank-one shift S^+ = (S + α u u')^{-1} - u u'/α
+    assert ctx.query("spectral_pinv") == n_spectral
     rtol = float(np.sqrt(np.finfo(float).eps))
     for d in range(sub.ndom):
         ref = np.linalg.pinv(blocks[d], rcond=rtol)
@@ -57,6 +61,48 @@ def test_device_assemble_local_schurs_and_pinv(pkg, ctx, fem, N, px, py, seed):
     if (px, py) == (3, 3):
         s = np.linalg.svd(blocks[4], compute_uv=False)
         assert s[-1] <= 1e-10 * s[0]                                           # the floating subdomain is singular
+
+
+@pytest.mark.parametrize("case", ["micro", "ragged"])
+def test_device_setup_against_the_reference_semantics(pkg, ctx, orc, fem, micro, ragged, case):
+    """a12 / a13 pinned to the ORACLE, i.e. to the reference's own semantics: `assemble_local_schurs` (EPDD.jl:667-695) applies
+    `apply_local_schur` to every unit vector with an UNPRECONDITIONED `IterativeSolvers.cg(...; reltol=1e-9)` interior solve
+    and mirrors the upper triangle; `prepare_neumann_neumann_schur_precond` (:1201-1220) is `pinv(rtol=sqrt(eps))`. The device
+    set-up solves the interiors exactly (deviation N2 of SURVEY.md §0): this test MEASURES that deviation — S_d within
+    1e-8 max|S_d| of the reference-semantics blocks, ΠS_d likewise — and checks that it does not reach the solver: NN-PCG
+    takes the same number of iterations with either set of blocks, on the device and in the oracle."""
+    from test_gpu_parity import assert_history
+    api = pkg.api
+    P = micro if case == "micro" else ragged
+    sub = P.sub
+    n = sub.n_Γ
+    Sd_ref, its = orc.assemble_local_schurs(P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, reltol=1e-9, return_iterations=True)
+    Pi_ref = orc.prepare_neumann_neumann_schur_precond(Sd_ref)
+    assert all(i > 0 for i in its)
+    setup = api.SchurSetup(ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd)
+    Sd_dev, _ = setup.run()
+    Sd = setup.blocks(Sd_dev)
+    Pi = setup.blocks(api.nn_pinv(ctx, sub.n_Γd, Sd_dev))
+    dev_S = max(np.abs(Sd[d] - Sd_ref[d]).max() / np.abs(Sd_ref[d]).max() for d in range(sub.ndom))
+    dev_P = max(np.abs(Pi[d] - Pi_ref[d]).max() / np.abs(Pi_ref[d]).max() for d in range(sub.ndom))
+    print(f"\n{case}: deviation N2 (exact interior solves vs cg to reltol 1e-9): S_d {dev_S:.2e}, pinv(S_d) {dev_P:.2e} (relative, max norm)")
+    assert dev_S <= 1e-8, dev_S
+    assert dev_P <= 1e-6, dev_P            # pinv amplifies by cond(S_d) restricted to the kept spectrum
+    for d in range(sub.ndom):
+        assert np.array_equal(Sd_ref[d], Sd_ref[d].T)
+    # the solver does not see the difference: same `it`, histories to the usual bar
+    So_ref = orc.apply_local_schurs_operator(Sd_ref, sub.gather_idx, n)
+    Mo_ref = orc.neumann_neumann_operator(Pi_ref, sub.gather_idx, sub.node_Γ_cnt)
+    want = orc.pcg(So_ref, P.b_schur, np.zeros(n), Mo_ref)
+    S_dev = api.LocalSchurs(ctx, [np.asfortranarray(b) for b in Sd], sub.gather_idx, sub.node_Γ_cnt)
+    M_dev = api.NeumannNeumannSchurPreconditioner(ctx, [np.asfortranarray(b) for b in Pi], sub.gather_idx, sub.node_Γ_cnt)
+    got = api.pcg(S_dev, P.b_schur, np.zeros(n), M_dev)
+    assert got[1] == want[1], (got[1], want[1])
+    assert np.allclose(got[2], want[2], rtol=1e-6, atol=1e-10 * want[2][0])      # blocks differ by 1e-9: histories follow
+    assert np.linalg.norm(got[0] - want[0]) <= 1e-6 * np.linalg.norm(want[0])
+    S_r = api.LocalSchurs(ctx, Sd_ref, sub.gather_idx, sub.node_Γ_cnt)
+    M_r = api.NeumannNeumannSchurPreconditioner(ctx, Pi_ref, sub.gather_idx, sub.node_Γ_cnt)
+    assert_history(api.pcg(S_r, P.b_schur, np.zeros(n), M_r), want)             # same blocks on both sides: the tight bar
 
 
 def test_realization_on_the_device_end_to_end(pkg, ctx, orc, fem):

@@ -413,3 +413,23 @@ def test_set_subdomains_matches_the_reference_loops(fem, orc, case):
     assert {int(g): int(sub.ind_Γ_g2l[g]) for g in sub.node_Γ} == ind_Γ_g2l
     if case.startswith("pie"):
         assert sub.node_Γ_cnt.max() >= 5
+
+
+def test_assemble_local_schurs_reference_semantics(orc, fem, micro):
+    """oracle.assemble_local_schurs (EPDD.jl:667-695: unit vectors through apply_local_schur with the unpreconditioned
+    interior cg at reltol 1e-9, upper triangle mirrored) against exact Schur complements: the inexact interior solve shows
+    as a relative difference of the order of reltol, and a tighter reltol closes it; prepare_nn is pinv(rtol=sqrt(eps))."""
+    P = micro
+    Sd9, its = orc.assemble_local_schurs(P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, reltol=1e-9, return_iterations=True)
+    Sd13 = orc.assemble_local_schurs(P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, reltol=1e-13)
+    for d in range(P.sub.ndom):
+        exact = P.Sd[d]
+        e9 = np.abs(Sd9[d] - exact).max() / np.abs(exact).max()
+        e13 = np.abs(Sd13[d] - exact).max() / np.abs(exact).max()
+        assert e13 <= 1e-11 and e9 <= 1e-8 and e13 <= e9
+        assert np.array_equal(Sd9[d], Sd9[d].T)
+        assert its[d] >= P.sub.n_Γd[d]                      # at least one interior iteration per unit vector
+    Pi = orc.prepare_neumann_neumann_schur_precond(Sd9)
+    for d in range(P.sub.ndom):
+        A = Sd9[d]
+        assert np.abs(A @ Pi[d] @ A - A).max() <= 1e-7 * np.abs(A).max()

@@ -270,9 +270,44 @@ def setup_measurement(api, ctx, P, S, M):
     ctx.synchronize()
     t_set = time.perf_counter() - t0
     err = max(float((b.cpu().numpy() - np.asarray(P.Sd[d])).__abs__().max() / np.abs(P.Sd[d]).max()) for d, b in enumerate(setup.blocks(Sd)))
-    return {"plan_once_s": round(t_plan, 3), "assemble_local_schurs_ms": round(t_S * 1e3, 1), "pinv_ms": round(t_pinv * 1e3, 1),
-            "set_blocks_ms": round(t_set * 1e3, 2), "max_rel_diff_vs_host_blocks": err,
-            "note": "S_d: block Gauss-Jordan level elimination (fp64 MFMA), all subdomains batched, one hipGraph replay; look-ahead pivots; pinv: the same inversion for blocks whose norm certificate shows full rank, rocSOLVER dsyevd otherwise"}
+    out = {"plan_once_s": round(t_plan, 3), "assemble_local_schurs_ms": round(t_S * 1e3, 1), "pinv_ms": round(t_pinv * 1e3, 1),
+           "set_blocks_ms": round(t_set * 1e3, 2), "max_rel_diff_vs_host_blocks": err,
+           "note": "S_d: block Gauss-Jordan level elimination (fp64 MFMA, upper-triangular tiles), all subdomains batched, one hipGraph replay; "
+                   "look-ahead pivots; pinv: the same inversion behind a norm certificate (floating blocks: rank-one shift), eigen-decomposition only beyond"}
+    # the matrix-free S-apply (apply_local_schurs, EPDD.jl:711-747) with the EXACT interior solve of the kept level inverses
+    # (mi_schur_setup_keep_levels) against the reference's own interior iteration on the device (IterativeSolvers.cg, reltol 1e-9)
+    try:
+        setup.keep_levels(True)
+        t0 = time.perf_counter()
+        Sd2, _ = setup.run(*vals, bI)
+        ctx.synchronize()
+        t_keep = time.perf_counter() - t0
+        Smf = api.MatrixFreeLocalSchurs(ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, sub.gather_idx, sub.node_Γ_cnt, None, reltol=1e-9)
+        v = torch.from_numpy(np.random.default_rng(0).standard_normal(sub.n_Γ)).cuda()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y_cg = Smf.apply(v)
+        ctx.synchronize()
+        t_cg = time.perf_counter() - t0
+        Smf.use_level_solver(setup)
+        Smf.apply(v); ctx.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            y_lv = Smf.apply(v)
+            ctx.synchronize()
+            ts.append(time.perf_counter() - t0)
+        y_as = S.apply(v)
+        ctx.synchronize()
+        scale = float(y_as.abs().max())
+        out["matrix_free_apply"] = {"interior_cg_reltol1e-9_ms": round(t_cg * 1e3, 1), "level_solves_ms": round(min(ts) * 1e3, 2),
+                                    "setup_with_kept_levels_ms": round(t_keep * 1e3, 1),
+                                    "rel_diff_level_vs_assembled": float((y_lv - y_as).abs().max()) / scale,
+                                    "rel_diff_cg_vs_assembled": float((y_cg - y_as).abs().max()) / scale}
+        setup.keep_levels(False)
+    except Exception as e:   # noqa: BLE001
+        out["matrix_free_apply"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def config5_measurement(args, api, fem, ctx, mesh, P, f, uex, nreals=50, check_first=3):
@@ -520,13 +555,17 @@ def main():
     coeff = np.exp(g)
     f = lambda x, y: -1.0 + 0 * x
     uex = lambda x, y: 0.734 + 0 * x
-    P = fem.build_schur_problem(args.N, args.px, args.py, coeff, f, uex, dom_slice=(lo, hi))
+    # S_d, the condensed right-hand side and ΠS_d = pinv(S_d) through the library's own device set-up (mi_schur_setup_run,
+    # mi_nn_pinv): the default command dispatches no kernel of another library (rocSOLVER / rocBLAS through torch faulted
+    # under `rocprofv3 --pmc`, profiles/r02_pmc_crash_stack.txt); MI355_SETUP_ON_HOST=1 keeps fem.py's host elimination
+    ctx = api.Context(local_rank)
+    hook = None if os.environ.get("MI355_SETUP_ON_HOST") else api.device_dense_setup(ctx)
+    P = fem.build_schur_problem(args.N, args.px, args.py, coeff, f, uex, dom_slice=(lo, hi), dense_setup=hook)
     n_Γ = P.sub.n_Γ
     n_free = int((mesh.point_marker == 0).sum())
     log(rank, f"set-up {time.time() - t0:.1f}s: free DoF={n_free} n_Γ={n_Γ} n_Γd={P.sub.n_Γd} local subdomains {lo}..{hi - 1}")
 
     # ---------------- device residents
-    ctx = api.Context(local_rank)
     if args.chunk >= 0:
         ctx.set_chunk(args.chunk)
     if multi:

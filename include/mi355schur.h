@@ -319,6 +319,18 @@ int mi_schur_setup_create(mi_ctx_t ctx, int64_t ndom, const int64_t *n_gamma_d, 
                           mi_setup_t *plan);
 int mi_schur_setup_run(mi_setup_t plan, const double *ii_val, const double *ig_val, const double *gg_val,
                        const double *b_I, double *Sd, double *w);
+/* Level solves — the interior solve of the matrix-free applies as the north-star words it ("the A_II^{-1} interior solve stays
+ * ... sparse Cholesky"): EXACT, on the device. mi_schur_setup_keep_levels(plan, 1) makes every following run keep the
+ * inverses Z_k of all breadth-first levels (block LDL' of A_IIdd; Σ n_level² doubles — 6.2 GB at config 3); then
+ * mi_schur_setup_interior_solve: u = A_IIdd \ f for ALL subdomains at once (f, u: concatenated interior vectors in the order
+ * of b_I), a forward and a backward sweep over the kept inverses, one hipGraph replay — in place of the reference's inexact
+ * `IterativeSolvers.cg(A_IIdd, rhs; reltol)` (EPDD.jl:609-619, 648-650, 813-815, 1021) and of its thousands of A_II SpMVs.
+ * mi_schur_matfree_interior_levels(op, plan): a matrix-free or global Schur operator built on the same subdomains uses
+ * these solves for every interior solve (apply, get_schur_rhs, get_subdomain_solutions); plan = NULL restores its own
+ * (callback / interior CG). The plan must outlive the operator's use of it; values are those of the plan's last run. */
+int mi_schur_setup_keep_levels(mi_setup_t plan, int on);
+int mi_schur_setup_interior_solve(mi_setup_t plan, const double *f, double *u);
+int mi_schur_matfree_interior_levels(mi_op_t op, mi_setup_t plan);
 int mi_schur_setup_destroy(mi_setup_t plan);
 int mi_nn_pinv(mi_ctx_t ctx, int64_t ndom, const int64_t *n_gamma_d, const double *Sd, double rtol, double *PiSd);
 int mi_dense_set_blocks(mi_op_t op, const double *blocks);

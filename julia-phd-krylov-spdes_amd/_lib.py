@@ -80,6 +80,9 @@ SIGNATURES = {
     "mi_ctx_peer_ready": [vp],
     "mi_ctx_set_exchange": [vp, C.c_int],
     "mi_ctx_query": [vp, C.c_int, i64p],
+    "mi_schur_setup_keep_levels": [vp, C.c_int],
+    "mi_schur_setup_interior_solve": [vp, vp, vp],
+    "mi_schur_matfree_interior_levels": [vp, vp],
     "mi_assembly_plan_create": [vp, i64, i64, i64p, C.c_int, f64p, f64p, f64p, f64p, i64, i64, i64p, i64p, C.POINTER(vp)],
     "mi_assembly_run": [vp, vp, vp],
     "mi_assembly_plan_destroy": [vp],

@@ -681,6 +681,27 @@ class SchurSetup:
         self.ctx._record(ii_val, ig_val, gg_val, b_I, Sd, w)
         return Sd, w
 
+    def keep_levels(self, on: bool = True) -> None:
+        """Every following `run` keeps the inverses of all elimination levels (`mi_schur_setup_keep_levels`): exact interior
+        solves `interior_solve(f)` and `MatrixFreeLocalSchurs.use_level_solver(self)`."""
+        check(self.ctx._L.mi_schur_setup_keep_levels(self._h, C.c_int(1 if on else 0)))
+
+    def interior_solve(self, f):
+        """u = A_IIdd \\ f for all subdomains (concatenated interior vectors, the order of b_I): exact, on the device."""
+        self.ctx._mode_for(f)
+        n = int(sum(self.n_Id))
+        kf, pf = self.ctx._ptr(f, n)
+        if _is_torch(f):
+            import torch
+            u = torch.empty_like(f)
+            pu = vp(u.data_ptr())
+        else:
+            u = np.empty(n)
+            pu = vp(u.ctypes.data)
+        check(self.ctx._L.mi_schur_setup_interior_solve(self._h, pf, pu))
+        self.ctx._record(f, u)
+        return u
+
     def blocks(self, Sd):
         """The list of n_Γd x n_Γd column-major blocks of a concatenated buffer (views)."""
         out, off = [], 0
@@ -720,6 +741,24 @@ def nn_pinv(ctx: Context, n_Γd, Sd, rtol: float = 0.0):
     return out
 
 
+def device_dense_setup(ctx: Context):
+    """`dense_setup` hook of `fem.build_schur_problem`: S_d, w_d (`assemble_local_schurs` + the condensed rhs of `get_schur_rhs`,
+    EPDD.jl:667-695, 853-861) and ΠS_d (`prepare_neumann_neumann_schur_precond`, :1201-1220) from this library's device set-up
+    (`mi_schur_setup_run`, `mi_nn_pinv`) — host arrays in and out."""
+    def run(A_II, A_IΓ, A_ΓΓ, b_Id, want_pinv):
+        setup = SchurSetup(ctx, A_II, A_IΓ, A_ΓΓ)
+        Sd, w = setup.run(b_I=np.concatenate(b_Id))
+        Sl = [np.asfortranarray(b) for b in setup.blocks(Sd)]
+        wl, off = [], 0
+        for n in setup.n_Γd:
+            wl.append(w[off:off + n].copy())
+            off += n
+        Pl = [np.asfortranarray(b) for b in setup.blocks(nn_pinv(ctx, setup.n_Γd, Sd))] if want_pinv else None
+        setup.close()
+        return Sl, wl, Pl
+    return run
+
+
 def _set_blocks(self, blocks):
     """New S_d / ΠS_d (one concatenated column-major buffer, numpy or torch CUDA) on this operator's maps (`mi_dense_set_blocks`)."""
     self.ctx._mode_for(blocks)
@@ -728,8 +767,16 @@ def _set_blocks(self, blocks):
     self.ctx._record(blocks)
 
 
+def _use_level_solver(self, setup: "SchurSetup" = None):
+    """Interior solves of this matrix-free / global Schur operator through the level inverses `setup` keeps (exact, device;
+    `mi_schur_matfree_interior_levels`); None: back to the operator's own callback / interior CG."""
+    check(self.ctx._L.mi_schur_matfree_interior_levels(self._h, setup._h if setup is not None else None))
+    self._level_setup = setup      # keep the plan alive
+
+
 LocalSchurs.set_blocks = _set_blocks
 NeumannNeumannSchurPreconditioner.set_blocks = _set_blocks
+MatrixFreeLocalSchurs.use_level_solver = _use_level_solver
 
 
 class GlobalSchur(Operator):
@@ -904,3 +951,6 @@ def initcg(A: Operator, b, x, W, maxit: int = 0, eps: float = EPS):
 def initpcg(A: Operator, b, x, M: Operator, W, maxit: int = 0, eps: float = EPS):
     """initpcg(A, b, x, M, W; maxit=0) (initcg.jl:106-160)."""
     return _solve("initpcg", A, M, b, x, W, maxit, eps)
+
+
+GlobalSchur.use_level_solver = _use_level_solver

@@ -983,6 +983,50 @@ int mi_schur_setup_run(mi_setup_t plan, const double *ii_val, const double *ig_v
     return MI_OK;
   });
 }
+int mi_schur_setup_keep_levels(mi_setup_t plan, int on) {
+  if (!plan) return fail(MI_ERR_BAD_ARG, "plan is NULL");
+  return guarded([&]() -> int {
+    plan->ctx->use();
+#ifdef MI355_EXPERIMENTAL
+    if (!plan->lanes.empty()) return fail(MI_ERR_BAD_ARG, "level solves belong to the Gauss-Jordan set-up (not MI355_SETUP_LIB=1)");
+#endif
+    gj_set_keep(*plan, on != 0);
+    return MI_OK;
+  });
+}
+int mi_schur_setup_interior_solve(mi_setup_t plan, const double *f, double *u) {
+  if (!plan || !f || !u) return fail(MI_ERR_BAD_ARG, "mi_schur_setup_interior_solve: NULL argument");
+  mi_ctx_s *c = plan->ctx;
+  return guarded([&]() -> int {
+    c->use();
+    DevBuf<double> s1, s2;
+    In fi(c, f, (size_t)plan->n_bi, s1);
+    InOut uo(c, u, (size_t)plan->n_bi, s2, false);
+    gj_level_solve(*plan, fi.dev, uo.dev);
+    uo.finish();
+    if (c->ptr_mode != MI_PTR_DEVICE) MI_HIP(hipStreamSynchronize(c->stream));
+    return MI_OK;
+  });
+}
+int mi_schur_matfree_interior_levels(mi_op_t op, mi_setup_t plan) {
+  if (!op || !op->impl) return fail(MI_ERR_BAD_ARG, "op is NULL");
+  return guarded([&]() -> int {
+    MatfreeSchurOp *mf = dynamic_cast<MatfreeSchurOp *>(op->impl.get());
+    GlobalSchurOp *gs = dynamic_cast<GlobalSchurOp *>(op->impl.get());
+    if (!mf && !gs) return fail(MI_ERR_BAD_ARG, "mi_schur_matfree_interior_levels: not a matrix-free Schur operator");
+    std::function<void(const double *, double *)> fn;
+    if (plan) {
+      if (plan->ctx != op->impl->ctx) return fail(MI_ERR_BAD_ARG, "plan and operator live on different contexts");
+      const size_t ni_tot = mf ? mf->ni_tot : gs->ni_tot;
+      const int nd = mf ? mf->maps.ndl : gs->ndom;
+      if ((long long)ni_tot != plan->n_bi || nd != plan->ndom)
+        return fail(MI_ERR_BAD_ARG, "plan and operator differ in their subdomains (%d with %lld interior nodes vs %d with %lld)", plan->ndom, plan->n_bi, nd, (long long)ni_tot);
+      fn = [plan](const double *f, double *u) { gj_level_solve(*plan, f, u); };
+    }
+    if (mf) mf->level_solver = fn; else gs->level_solver = fn;
+    return MI_OK;
+  });
+}
 int mi_schur_setup_destroy(mi_setup_t plan) {
   if (!plan) return MI_OK;
   return guarded([&]() -> int {

@@ -2,6 +2,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
 #include <numeric>
 
 #include "common.hpp"
@@ -812,6 +813,9 @@ struct MatfreeSchurOp : Operator {
   int ni_tot = 0;
   mi_interior_solve_fn solve; void *user;
   std::unique_ptr<InteriorCg> icg;
+  // exact interior solve by the level inverses a set-up plan keeps (mi_schur_matfree_interior_levels; setup_gj.hpp): when set,
+  // it replaces the callback / the interior CG in every interior solve of this operator
+  std::function<void(const double *, double *)> level_solver;
   DevBuf<double> xcat, rhs, sol, t1, yloc, t2;
   DevBuf<int> ig_perm;  // A_IG.val[k] = (caller's concatenated A_IΓ values)[ig_perm[k]]  (set_values)
   HostStage stage;
@@ -870,7 +874,9 @@ struct MatfreeSchurOp : Operator {
       MI_HIP(hipGetLastError());
       A_IG.launch(0, xcat.p, nullptr, rhs.p, nullptr, s);
       A_GG.launch(0, xcat.p, nullptr, t1.p, nullptr, s);
-      if (icg) {
+      if (level_solver) {
+        level_solver(rhs.p, sol.p);
+      } else if (icg) {
         icg->solve(rhs.p, sol.p);
       } else {
         MI_HIP(hipMemcpyAsync(stage.rhs, rhs.p, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
@@ -904,7 +910,9 @@ struct MatfreeSchurOp : Operator {
   void schur_rhs(const double *b_I, const double *b_gamma, double *out) {
     hipStream_t s = ctx->stream;
     if (maps.nloc) {
-      if (icg) {
+      if (level_solver) {
+        level_solver(b_I, sol.p);
+      } else if (icg) {
         icg->solve(b_I, sol.p);
       } else {
         MI_HIP(hipMemcpyAsync(stage.rhs, b_I, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
@@ -928,7 +936,9 @@ struct MatfreeSchurOp : Operator {
     hipLaunchKernelGGL(k_gather, dim3(vec_grid(maps.nloc)), dim3(NT), 0, s, maps.nloc, maps.gidx.p, u_gamma, xcat.p);
     MI_HIP(hipGetLastError());
     A_IG.launch(1, xcat.p, b_I, rhs.p, nullptr, s);  // rhs = b_I - A_IΓ u_Γd
-    if (icg) {
+    if (level_solver) {
+      level_solver(rhs.p, u_I);
+    } else if (icg) {
       icg->solve(rhs.p, u_I);
     } else {
       MI_HIP(hipMemcpyAsync(stage.rhs, rhs.p, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
@@ -966,6 +976,7 @@ struct GlobalSchurOp : Operator {
   HostStage stage;
 
   std::unique_ptr<InteriorCg> icg;  // device interior solve (no callback): IterativeSolvers.cg restated, all subdomains at once
+  std::function<void(const double *, double *)> level_solver;   // as in MatfreeSchurOp
 
   GlobalSchurOp(mi_ctx_s *c, int64_t ndom_, int64_t n_gamma, const int64_t *n_i, const int64_t *const *ig_ptr,
                 const int64_t *const *ig_idx, const double *const *ig_val, const int64_t *gg_ptr, const int64_t *gg_idx,
@@ -1003,7 +1014,9 @@ struct GlobalSchurOp : Operator {
     hipStream_t s = ctx->stream;
     A_GG.launch(0, x, nullptr, y, nullptr, s);  // Sx = A_ΓΓ * x
     for (int d = 0; d < ndom; ++d) A_IG[d].launch(0, x, nullptr, rhs.p + ioff[d], nullptr, s);
-    if (icg) {
+    if (level_solver) {
+      level_solver(rhs.p, sol.p);
+    } else if (icg) {
       icg->solve(rhs.p, sol.p);
     } else {
       MI_HIP(hipMemcpyAsync(stage.rhs, rhs.p, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
@@ -1018,6 +1031,7 @@ struct GlobalSchurOp : Operator {
   // A_IId^{-1} v for every subdomain (device pointers; v, out: concatenated over the subdomains)
   void interior_solve(const double *v, double *out) {
     hipStream_t s = ctx->stream;
+    if (level_solver) { level_solver(v, out); return; }
     if (icg) { icg->solve(v, out); return; }
     MI_HIP(hipMemcpyAsync(stage.rhs, v, sizeof(double) * ni_tot, hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));

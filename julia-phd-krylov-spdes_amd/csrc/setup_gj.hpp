@@ -33,6 +33,10 @@ struct GjStep {             // one per (step, subdomain); n0 == 0: the subdomain
   long long d_e0, d_e1;     // entry list of A_kk
   int b_off;                // offset of this level's nodes in `perm` (gather of b_k)
   int nb;                   // GJ block steps of this level = ceil(n0 / GJ_B)
+  // level solves (the inverses Z_k kept after a run): where this level's Z lives in `zstore`, and the ROW form of the
+  // coupling block C = A_{this level, next shallower level} (rows = this level's nodes) for the back-substitution
+  long long zoff;
+  int rptr;
 };
 struct GjDom {              // per subdomain
   double *T, *Z[2], *y, *g[2], *P;
@@ -55,8 +59,15 @@ struct GjState {
   DevBuf<double> in_ii, in_ig, in_gg, in_bi, out_S, out_w;   // plan-owned I/O of the captured graph
   hipGraphExec_t graph[2] = {nullptr, nullptr};               // without / with right-hand side
   bool graph_failed = false;
+  // level solves: A_IIdd \ f for all subdomains by forward / backward sweeps over the kept level inverses
+  bool keep = false;
+  DevBuf<double> zstore, gstore, ustore, sv_in, sv_out;
+  DevBuf<int> r_ptr, r_col, r_src;
+  hipGraphExec_t solve_graph = nullptr;
+  bool have_levels = false;                                   // a run with keep == true has filled zstore
   ~GjState() {
     for (auto &g : graph) if (g) (void)hipGraphExecDestroy(g);
+    if (solve_graph) (void)hipGraphExecDestroy(solve_graph);
   }
 };
 
@@ -248,11 +259,21 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
     else if (bx == td && by == td) bx = by = 0;
   }
   const bool special = ahead && bx == td && by == td;
+  // SYMMETRY. With σ(i) = -1 for the indices already swept (i < k0) and +1 otherwise, the matrix between two block steps
+  // satisfies M[j,i] = σ(i) σ(j) M[i,j] (the inverse pivot block and the trailing part are symmetric, the row panel P A_Kj
+  // and the column panel -A_iK P are each other's negative transpose; induction over the steps, P symmetric). Only the
+  // tiles on and above the diagonal are computed; an off-diagonal tile also writes its mirror image (transposed through
+  // LDS so that both stores are 128-byte segments). Storage stays full: the pick kernels and the next step's panel loads
+  // read any entry.
+  if (bx > by) return;
   const int i0 = bx * GJ_T, j0 = by * GJ_T;
-  __shared__ double Pm[GJ_B][GJ_B + 1];          // P[r][c]
   // 42 KB of LDS: three workgroups per CU (with A[K, J] and R in buffers of their own, 58 KB, it was two)
-  __shared__ double R[GJ_B][GJ_T + 1];           // A[K, J] (32 x 64) first, then R = P * A[K, J], then (look-ahead tile) the next pivot block
-  __shared__ double Cc[GJ_T][GJ_B + 1];          // A[I, K]           (64 x 32)
+  constexpr int LDS_PM = GJ_B * (GJ_B + 1), LDS_R = GJ_B * (GJ_T + 1), LDS_CC = GJ_T * (GJ_B + 1);
+  static_assert(LDS_R + LDS_CC >= GJ_T * (GJ_T + 1), "the mirror image of a tile is staged in the R and Cc buffers");
+  __shared__ double lds[LDS_PM + LDS_R + LDS_CC];
+  double (&Pm)[GJ_B][GJ_B + 1] = *reinterpret_cast<double (*)[GJ_B][GJ_B + 1]>(lds);                   // P[r][c]
+  double (&R)[GJ_B][GJ_T + 1] = *reinterpret_cast<double (*)[GJ_B][GJ_T + 1]>(lds + LDS_PM);           // A[K, J] (32 x 64) first, then R = P * A[K, J], then (look-ahead tile) the next pivot block
+  double (&Cc)[GJ_T][GJ_B + 1] = *reinterpret_cast<double (*)[GJ_T][GJ_B + 1]>(lds + LDS_PM + LDS_R);  // A[I, K]           (64 x 32)
   double (&Ak)[GJ_B][GJ_T + 1] = R;
   const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = l & 15, lk = l >> 4;
   const double *Pcur = dm.P + (kb & 1) * (GJ_B * GJ_B);
@@ -321,6 +342,28 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
       O[i + (size_t)j * n] = val;
       acc[jt][v] = val;
     }
+  if (bx != by) {                                // the mirror image: M[j,i] = σ'(i) σ'(j) M[i,j], σ' = -1 below k1 (swept after this step)
+    __syncthreads();                             // R, Cc, Pm are read for the last time above
+    double *T = lds + LDS_PM;                    // [GJ_T][GJ_T + 1]
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int jl = 16 * jt + lk + 4 * v, j = j0 + jl;
+        const double sg = ((i < k1) != (j < k1)) ? -1.0 : 1.0;
+        T[jl * (GJ_T + 1) + 16 * wv + lc] = sg * acc[jt][v];
+      }
+    __syncthreads();
+    const int r = j0 + 16 * wv + lc;             // row of the mirror tile (a column index of this tile)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int cl = 16 * jt + lk + 4 * v, cg = i0 + cl;
+        if (r < n && cg < n) O[r + (size_t)cg * n] = T[(16 * wv + lc) * (GJ_T + 1) + cl];
+      }
+    return;
+  }
   if (!special) return;
   __syncthreads();                               // R is read for the last time above: it becomes the landing zone of the next pivot block
 #pragma unroll
@@ -398,6 +441,91 @@ __global__ __launch_bounds__(256) void k_gj_final_w(int ndom, const GjDom *__res
   }
   w[dm.w_off + j] = s;
 }
+// ---- level solves. After a run with `keep`, zstore holds Z_k = T_k^{-1} of every level of every subdomain, and
+//     A_IIdd \ f   =   forward:  g_m = f_m,  g_k = f_k - C_k' (Z_{k+1} g_{k+1})        (deepest level first: the run's own recursion)
+//                      backward: u_0 = Z_0 g_0,  u_{k+1} = Z_{k+1} (g_{k+1} - C_k u_k)  (C_k = A_{k+1,k})
+// is an EXACT interior solve (block LDL' over the breadth-first levels): two streams of the kept inverses instead of the
+// thousands of A_II SpMVs of the reference's `IterativeSolvers.cg` (EPDD.jl:648-650).
+__global__ __launch_bounds__(256) void k_gj_keep(int step, int ndom, const GjStep *__restrict__ steps, const GjDom *__restrict__ doms,
+                                                 double *__restrict__ zstore) {
+  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
+  if (st.n0 == 0) return;
+  const GjDom dm = doms[blockIdx.z];
+  const double *src = GJ_Z(dm, st.nb & 1);
+  double *dst = zstore + st.zoff;
+  const long long tot = (long long)st.n0 * st.n0;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) dst[e] = src[e];
+}
+// y = Z_{k+1} g_{k+1} (the deeper level, handled one step earlier)
+__global__ __launch_bounds__(256) void k_lv_zg(int step, int ndom, const GjStep *__restrict__ steps, const GjDom *__restrict__ doms,
+                                               const double *__restrict__ zstore, const double *__restrict__ gstore) {
+  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
+  if (st.n0 == 0 || st.n1 == 0 || (int)blockIdx.x * 64 >= st.n1) return;
+  const GjStep sp = steps[(size_t)(step - 1) * ndom + blockIdx.z];
+  gj_gemv64(zstore + sp.zoff, st.n1, gstore + sp.b_off, doms[blockIdx.z].y);
+}
+// g_k = f_k - C_k' y  (f in the caller's interior order, g in level order)
+__global__ __launch_bounds__(256) void k_lv_g(int step, int ndom, const GjStep *__restrict__ steps, const GjDom *__restrict__ doms,
+                                              const int *__restrict__ c_ptr, const int *__restrict__ c_row, const int *__restrict__ c_src,
+                                              const double *__restrict__ ii_val, const int *__restrict__ perm, const double *__restrict__ f,
+                                              double *__restrict__ gstore) {
+  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= st.n0) return;
+  double v = f[perm[st.b_off + j]];
+  if (st.n1 > 0) {
+    const double *y = doms[blockIdx.z].y;
+    const int *cp = c_ptr + st.cptr;
+    double s2 = 0.0;
+    for (int p = cp[j]; p < cp[j + 1]; ++p) s2 += ii_val[c_src[p]] * y[c_row[p]];
+    v -= s2;
+  }
+  gstore[st.b_off + j] = v;
+}
+// u = Z (g - C u_shallower) for the level of `step` (64 rows per workgroup; the operand is formed in LDS first: every
+// workgroup needs all of it). last == 1: the shallowest level, u_0 = Z_0 g_0.
+constexpr int LV_MAX = 2048;
+__global__ __launch_bounds__(256) void k_lv_back(int step, int last, int ndom, const GjStep *__restrict__ steps,
+                                                 const double *__restrict__ zstore, const double *__restrict__ gstore,
+                                                 const int *__restrict__ r_ptr, const int *__restrict__ r_col, const int *__restrict__ r_src,
+                                                 const double *__restrict__ ii_val, double *__restrict__ ustore) {
+  const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
+  const int n = st.n0;
+  if (n == 0 || (int)blockIdx.x * 64 >= n) return;
+  __shared__ double t[LV_MAX];
+  __shared__ double part[4][64];
+  const double *g = gstore + st.b_off;
+  if (last) {
+    for (int i = threadIdx.x; i < n; i += 256) t[i] = g[i];
+  } else {
+    const GjStep sn = steps[(size_t)(step + 1) * ndom + blockIdx.z];      // the shallower level: its u is known
+    const double *us = ustore + sn.b_off;
+    const int *rp = r_ptr + st.rptr;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      double s2 = 0.0;
+      for (int p = rp[i]; p < rp[i + 1]; ++p) s2 += ii_val[r_src[p]] * us[r_col[p]];
+      t[i] = g[i] - s2;
+    }
+  }
+  __syncthreads();
+  const double *Z = zstore + st.zoff;
+  const int r = blockIdx.x * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6;
+  double s2 = 0.0;
+  if (r < n)
+    for (int b0 = wv; b0 < n; b0 += 16) {
+      double z[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int b = b0 + 4 * k; z[k] = b < n ? Z[r + (size_t)b * n] : 0.0; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int b = b0 + 4 * k; if (b < n) s2 += z[k] * t[b]; }
+    }
+  part[wv][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (threadIdx.x < 64 && r < n) ustore[st.b_off + r] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_lv_scatter(long long n, const int *__restrict__ perm, const double *__restrict__ ustore, double *__restrict__ u) {
+  for (long long q = blockIdx.x * 256ll + threadIdx.x; q < n; q += (long long)gridDim.x * 256) u[perm[q]] = ustore[q];
+}
 #pragma clang fp contract(off)
 
 inline void gj_build(mi_setup_s &P) {
@@ -474,6 +602,7 @@ inline void gj_enqueue(mi_setup_s &P, hipStream_t s, const double *ii, const dou
       if (kb == 0) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nd), dim3(64), 0, s, step, kb, nd, st, dm);   // later pivots: look-ahead in the update
       hipLaunchKernelGGL(k_gj_update, dim3(cdiv(nm, GJ_T), cdiv(nm, GJ_T), nd), dim3(256), 0, s, step, kb, nd, st, dm);
     }
+    if (G.keep) hipLaunchKernelGGL(k_gj_keep, dim3(std::min(1024, cdiv(nm * nm, 1024)), 1, nd), dim3(256), 0, s, step, nd, st, dm, G.zstore.p);
   }
   const int ngm = std::max(1, G.ngmax);
   nm = std::max(1, G.nmax);
@@ -487,15 +616,110 @@ inline void gj_enqueue(mi_setup_s &P, hipStream_t s, const double *ii, const dou
   MI_HIP(hipGetLastError());
 }
 
+// Keep the level inverses of every following run (mi_schur_setup_keep_levels): storage for all Z_k (Σ n_level² doubles: 6.2 GB
+// at config 3 — this is what 288 GB of HBM are for), the row form of the coupling blocks for the back-substitution, and
+// new graphs (the run now ends every step with a copy of the level's inverse).
+inline void gj_set_keep(mi_setup_s &P, bool on) {
+  if (!P.gj) gj_build(P);
+  GjState &G = *P.gj;
+  if (G.keep == on) return;
+  MI_HIP(hipStreamSynchronize(P.ctx->stream));
+  for (auto &g : G.graph) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+  if (G.solve_graph) { (void)hipGraphExecDestroy(G.solve_graph); G.solve_graph = nullptr; }
+  G.keep = on; G.have_levels = false;
+  if (!on) { G.zstore.release(); G.gstore.release(); G.ustore.release(); G.sv_in.release(); G.sv_out.release(); return; }
+  if (G.nmax > LV_MAX) raise(MI_ERR_BAD_ARG, "level solves: a level of %d nodes exceeds the %d the back-substitution kernel stages", G.nmax, LV_MAX);
+  const int nd = P.ndom;
+  long long ztot = 0;
+  std::vector<int> rp, rc, rs;
+  for (int d = 0; d < nd; ++d) {
+    const SetupDom &D = P.dom[d];
+    if (D.nlev == 0) continue;
+    if (D.lev_off[D.nlev] != D.n_i) raise(MI_ERR_BAD_ARG, "level solves: subdomain %d has interior nodes that are not connected to its interface", d);
+    for (int k = 0; k < D.nlev; ++k) {
+      GjStep &st = G.steps_h[(size_t)(G.nsteps - 1 - k) * nd + d];
+      st.zoff = ztot;
+      ztot += ((long long)st.n0 * st.n0 + 31) / 32 * 32;
+      st.rptr = 0;
+      if (k == 0) continue;
+      // rows of C_{k-1} = A_{k, k-1}: from its column form (columns = nodes of level k-1)
+      const int nr = st.n0, nc = D.lev_off[k] - D.lev_off[k - 1];
+      const int *cp = P.c_ptr_h.data() + D.cptr_off[k - 1];
+      std::vector<std::vector<std::pair<int, int>>> rows(nr);
+      for (int j = 0; j < nc; ++j)
+        for (int p = cp[j]; p < cp[j + 1]; ++p) rows[P.c_row_h[p]].push_back({j, P.c_src_h[p]});
+      st.rptr = (int)rp.size();
+      for (int i = 0; i < nr; ++i) {
+        rp.push_back((int)rc.size());
+        for (auto &e : rows[i]) { rc.push_back(e.first); rs.push_back(e.second); }
+      }
+      rp.push_back((int)rc.size());
+    }
+  }
+  hipStream_t s = P.ctx->stream;
+  G.steps.upload(G.steps_h, s);
+  G.r_ptr.upload(rp, s); G.r_col.upload(rc, s); G.r_src.upload(rs, s);
+  G.zstore.alloc((size_t)ztot + 32);
+  G.gstore.alloc((size_t)P.n_bi + 1); G.ustore.alloc((size_t)P.n_bi + 1);
+  G.sv_in.alloc((size_t)P.n_bi + 1); G.sv_out.alloc((size_t)P.n_bi + 1);
+}
+inline void gj_level_enqueue(mi_setup_s &P, hipStream_t s, const double *f, double *u) {
+  GjState &G = *P.gj;
+  const int nd = P.ndom;
+  const GjStep *st = G.steps.p;
+  const GjDom *dm = G.doms.p;
+  auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+  const double *ii = G.in_ii.p;   // the values of the last run
+  for (int step = 0; step < G.nsteps; ++step) {
+    const int nm = G.n_step[step];
+    if (step > 0) hipLaunchKernelGGL(k_lv_zg, dim3(cdiv(nm, 64), 1, nd), dim3(256), 0, s, step, nd, st, dm, G.zstore.p, G.gstore.p);
+    hipLaunchKernelGGL(k_lv_g, dim3(cdiv(nm, 256), 1, nd), dim3(256), 0, s, step, nd, st, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ii, P.perm.p, f, G.gstore.p);
+  }
+  for (int step = G.nsteps - 1; step >= 0; --step) {
+    const int nm = G.n_step[step];
+    hipLaunchKernelGGL(k_lv_back, dim3(cdiv(nm, 64), 1, nd), dim3(256), 0, s, step, step == G.nsteps - 1 ? 1 : 0, nd, st, G.zstore.p, G.gstore.p,
+                       G.r_ptr.p, G.r_col.p, G.r_src.p, ii, G.ustore.p);
+  }
+  hipLaunchKernelGGL(k_lv_scatter, dim3(std::min<long long>(4096, std::max<long long>(1, (P.n_bi + 255) / 256))), dim3(256), 0, s, (long long)P.n_bi,
+                     P.perm.p, G.ustore.p, u);
+  MI_HIP(hipGetLastError());
+}
+// u = A_II \ f for all subdomains (concatenated interior vectors in the caller's order), device pointers
+inline void gj_level_solve(mi_setup_s &P, const double *f, double *u) {
+  if (!P.gj || !P.gj->keep || !P.gj->have_levels) raise(MI_ERR_BAD_ARG, "level solves need mi_schur_setup_keep_levels(plan, 1) and a run after it");
+  GjState &G = *P.gj;
+  hipStream_t s = P.ctx->stream;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  if (cap != hipStreamCaptureStatusNone || env_int("MI355_SETUP_NO_GRAPH", 0)) { gj_level_enqueue(P, s, f, u); return; }   // inside somebody's capture: plain launches
+  if (!G.solve_graph) {
+    hipGraph_t gr = nullptr;
+    MI_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    try { gj_level_enqueue(P, s, G.sv_in.p, G.sv_out.p); } catch (...) { (void)hipStreamEndCapture(s, &gr); if (gr) (void)hipGraphDestroy(gr); throw; }
+    MI_HIP(hipStreamEndCapture(s, &gr));
+    hipError_t e = hipGraphInstantiate(&G.solve_graph, gr, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(gr);
+    if (e != hipSuccess) { G.solve_graph = nullptr; raise(MI_ERR_HIP, "level solves: hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+  }
+  MI_HIP(hipMemcpyAsync(G.sv_in.p, f, sizeof(double) * (size_t)P.n_bi, hipMemcpyDeviceToDevice, s));
+  MI_HIP(hipGraphLaunch(G.solve_graph, s));
+  MI_HIP(hipMemcpyAsync(u, G.sv_out.p, sizeof(double) * (size_t)P.n_bi, hipMemcpyDeviceToDevice, s));
+}
+
 inline void gj_run(mi_setup_s &P, const double *ii_val, const double *ig_val, const double *gg_val, const double *bI, double *Sd, double *w) {
   if (!P.gj) gj_build(P);
   GjState &G = *P.gj;
+  if (G.keep) G.have_levels = true;
   hipStream_t s = P.ctx->stream;
   const bool rhs = bI != nullptr && w != nullptr;
   auto cp = [&](double *dst, const double *src, long long cnt) {
     if (cnt > 0) MI_HIP(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToDevice, s));
   };
-  if (G.graph_failed || env_int("MI355_SETUP_NO_GRAPH", 0)) { gj_enqueue(P, s, ii_val, ig_val, gg_val, rhs ? bI : nullptr, Sd, w); return; }
+  if (G.graph_failed || env_int("MI355_SETUP_NO_GRAPH", 0)) {
+    if (G.keep) cp(G.in_ii.p, ii_val, P.n_ii);   // the level solves read the coupling values from the plan's copy
+    gj_enqueue(P, s, ii_val, ig_val, gg_val, rhs ? bI : nullptr, Sd, w);
+    return;
+  }
   hipGraphExec_t &ex = G.graph[rhs ? 1 : 0];
   if (!ex) {
     hipGraph_t gr = nullptr;
@@ -511,6 +735,7 @@ inline void gj_run(mi_setup_s &P, const double *ii_val, const double *ig_val, co
     if (!ok) {
       (void)hipGetLastError();
       ex = nullptr; G.graph_failed = true;
+      if (G.keep) cp(G.in_ii.p, ii_val, P.n_ii);
       gj_enqueue(P, s, ii_val, ig_val, gg_val, rhs ? bI : nullptr, Sd, w);
       return;
     }

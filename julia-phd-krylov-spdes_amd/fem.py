@@ -858,7 +858,8 @@ class SchurProblem:
 
 def build_schur_problem(N: int, px: int, py: int, coeff: Coeff, f, uexact,
                         assemble: bool = True, precond: bool = True, dom_slice=None,
-                        mesh: Optional[Mesh] = None, partition=None, blocks=None, sub: Optional[Subdomains] = None) -> SchurProblem:
+                        mesh: Optional[Mesh] = None, partition=None, blocks=None, sub: Optional[Subdomains] = None,
+                        dense_setup=None) -> SchurProblem:
     """Example03:45-150 set-up flow on the synthetic mesh (mesh → partition → maps →
     local blocks → b_schur → assembled S_d → Neumann-Neumann pseudo-inverses).
 
@@ -886,13 +887,21 @@ def build_schur_problem(N: int, px: int, py: int, coeff: Coeff, f, uexact,
     Sd = Pi = None
     if assemble:
         # one elimination per subdomain gives S_d and the condensed rhs (get_schur_rhs, EPDD.jl:835-864)
-        Sl, wl = assemble_local_schurs([A_II[d] for d in loc], [A_IΓ[d] for d in loc], [A_ΓΓ[d] for d in loc],
-                                       b_Id=[b_Id[d] for d in loc])
+        # `dense_setup(A_II, A_IΓ, A_ΓΓ, b_Id, want_pinv) -> (S_d list, w_d list, ΠS_d list | None)`: e.g. the device set-up of the
+        # library (api.device_dense_setup: mi_schur_setup_run + mi_nn_pinv) in place of this module's host elimination
+        Pl = None
+        if dense_setup is not None:
+            Sl, wl, Pl = dense_setup([A_II[d] for d in loc], [A_IΓ[d] for d in loc], [A_ΓΓ[d] for d in loc],
+                                     [b_Id[d] for d in loc], precond)
+        else:
+            Sl, wl = assemble_local_schurs([A_II[d] for d in loc], [A_IΓ[d] for d in loc], [A_ΓΓ[d] for d in loc],
+                                           b_Id=[b_Id[d] for d in loc])
         for d in loc:
             b_schur[sub.gather_idx[d]] -= wl[d - lo]
         Sd = [Sl[d - lo] if lo <= d < hi else None for d in range(sub.ndom)]
         if precond:
-            Pl = prepare_neumann_neumann_schur_precond(Sl)
+            if Pl is None:
+                Pl = prepare_neumann_neumann_schur_precond(Sl)
             Pi = [Pl[d - lo] if lo <= d < hi else None for d in range(sub.ndom)]
     else:
         for d in loc:                           # get_schur_rhs with sparse direct interior solves

@@ -332,7 +332,15 @@ def test_rccl_single_rank_communicator(pkg, ctx, orc, micro):
         ref = api.pcg(S1, P.b_schur, np.zeros(n), M1)
     finally:
         del os.environ["MI355_NO_FOLD"]
-    assert got[1] == ref[1] and np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0])
+    # both "sharded": the folded loop with an exchange behind each launch (round 3; per-row partial dots: re-associated) ...
+    assert got[1] == ref_fold[1] and np.allclose(got[2], ref_fold[2], rtol=1e-9, atol=1e-13 * ref_fold[2][0])
+    # ... and, on request, the 4-launch loop: bit-identical to the same loop form without a communicator
+    os.environ["MI355_NO_FOLD_SHARDED_NN"] = "1"
+    try:
+        got4 = api.pcg(S, P.b_schur, np.zeros(n), M)
+    finally:
+        del os.environ["MI355_NO_FOLD_SHARDED_NN"]
+    assert got4[1] == ref[1] and np.array_equal(got4[2], ref[2]) and np.array_equal(got4[0], ref[0])
     gf = api.pcg(S, P.b_schur, np.zeros(n), Mr)   # (a "sharded" S may be tiled differently: partial dots re-associated)
     assert gf[1] == ref_fold[1] and np.allclose(gf[2], ref_fold[2], rtol=1e-9, atol=1e-13 * ref_fold[2][0])
     v = np.random.default_rng(1).standard_normal(n)

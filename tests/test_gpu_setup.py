@@ -181,3 +181,50 @@ def test_full_size_device_setup(pkg, ctx, fem):
     Pib = [b.cpu().numpy() for b in setup.blocks(Pi)]
     for d in (0, 1):
         assert np.abs(Pib[d] - P.ΠSd[d]).max() <= 1e-6 * np.abs(P.ΠSd[d]).max()
+
+
+@pytest.mark.parametrize("N,px,py,seed", [(50, 3, 2, 7), (90, 4, 2, 5)])
+def test_level_solves_exact_interior_solve_on_the_device(pkg, ctx, orc, fem, N, px, py, seed):
+    """`mi_schur_setup_keep_levels` / `mi_schur_setup_interior_solve` / `mi_schur_matfree_interior_levels`: the interior solve
+    of the matrix-free applies (EPDD.jl:648-650: `IterativeSolvers.cg(A_IIdd, A_IΓdd xd; reltol)`) done EXACTLY on the device by
+    sweeps over the level inverses the set-up keeps. Against sparse direct solves on the host (SuperLU), the oracle's
+    matrix-free apply with those solves, the assembled operator (Example03:175), and `get_schur_rhs` /
+    `get_subdomain_solutions` through the same operator."""
+    api = pkg.api
+    mesh = fem.get_mesh(N)
+    P = fem.build_schur_problem(N, px, py, lognormal_coeff(fem, mesh.points, seed), f_m1, u0734)
+    sub = P.sub
+    n = sub.n_Γ
+    setup = api.SchurSetup(ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd)
+    setup.keep_levels(True)
+    Sd, _ = setup.run(b_I=np.concatenate(P.b_Id))
+    for d, blk in enumerate(setup.blocks(Sd)):                          # keeping the levels does not change the run
+        assert np.abs(blk - P.Sd[d]).max() <= 1e-10 * np.abs(P.Sd[d]).max()
+    rng = np.random.default_rng(1)
+    f = rng.standard_normal(int(sum(setup.n_Id)))
+    u = setup.interior_solve(f)
+    off = 0
+    for d in range(sub.ndom):
+        ni = setup.n_Id[d]
+        ref = P.solvers[d](f[off:off + ni])
+        assert np.abs(u[off:off + ni] - ref).max() <= 1e-10 * np.abs(ref).max(), d
+        off += ni
+    # the matrix-free operator with these solves: equals the oracle's with sparse direct solves, and the assembled operator
+    Smf = api.MatrixFreeLocalSchurs(ctx, P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, sub.gather_idx, sub.node_Γ_cnt, None, reltol=1e-9)
+    Smf.use_level_solver(setup)
+    So_mf = orc.apply_local_schurs_matfree_operator(P.A_IIdd, P.A_IΓdd, P.A_ΓΓdd, sub.gather_idx, n, P.solvers)
+    So = orc.apply_local_schurs_operator(P.Sd, sub.gather_idx, n)
+    v = rng.standard_normal(n)
+    y = Smf * v
+    assert np.abs(y - So_mf * v).max() <= 1e-10 * np.abs(y).max()
+    assert np.abs(y - So * v).max() <= 1e-10 * np.abs(y).max()          # Example03:175 with an exact interior solve
+    b_schur = Smf.schur_rhs(np.concatenate(P.b_Id), P.b_Γ)              # get_schur_rhs, EPDD.jl:835-864
+    assert np.abs(b_schur - P.b_schur).max() <= 1e-10 * np.abs(P.b_schur).max()
+    # a Schur solve with the matrix-free operator, then the interiors (Example03:196-204)
+    M = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, sub.gather_idx, sub.node_Γ_cnt)
+    x, it, res = api.pcg(Smf, b_schur, np.zeros(n), M)
+    want = orc.pcg(So, P.b_schur, np.zeros(n), orc.neumann_neumann_operator(P.ΠSd, sub.gather_idx, sub.node_Γ_cnt))
+    assert it == want[1] and np.linalg.norm(x - want[0]) <= 1e-6 * np.linalg.norm(want[0])
+    Smf.use_level_solver(None)                                          # back to the interior CG of the operator
+    y2 = Smf * v
+    assert np.abs(y2 - y).max() <= 1e-7 * np.abs(y).max()

@@ -269,9 +269,8 @@ def setup_measurement(api, ctx, P, S, M):
     S.set_blocks(Sd); M.set_blocks(Pi)
     ctx.synchronize()
     t_set = time.perf_counter() - t0
-    err = max(float((b.cpu().numpy() - np.asarray(P.Sd[d])).__abs__().max() / np.abs(P.Sd[d]).max()) for d, b in enumerate(setup.blocks(Sd)))
     out = {"plan_once_s": round(t_plan, 3), "assemble_local_schurs_ms": round(t_S * 1e3, 1), "pinv_ms": round(t_pinv * 1e3, 1),
-           "set_blocks_ms": round(t_set * 1e3, 2), "max_rel_diff_vs_host_blocks": err,
+           "set_blocks_ms": round(t_set * 1e3, 2),
            "note": "S_d: block Gauss-Jordan level elimination (fp64 MFMA, upper-triangular tiles), all subdomains batched, one hipGraph replay; "
                    "look-ahead pivots; pinv: the same inversion behind a norm certificate (floating blocks: rank-one shift), eigen-decomposition only beyond"}
     # the matrix-free S-apply (apply_local_schurs, EPDD.jl:711-747) with the EXACT interior solve of the kept level inverses

@@ -23,8 +23,14 @@
 
 namespace mi {
 
-constexpr int GJ_B = 32;    // pivot block
+#ifndef MI355_GJ_B
+#define MI355_GJ_B 64
+#endif
+constexpr int GJ_B = MI355_GJ_B;   // pivot block: 64 (one full-matrix pass per 64 eliminated rows; its inverse from two 32-wide
+                                   // register inversions and 32 x 32 matrix-core products) or 32 (round 2's form)
+constexpr int GJ_H = 32;    // rows one wave inverts in registers
 constexpr int GJ_T = 64;    // tile of the update launch (256 threads, 4 x 4 outputs each)
+static_assert(GJ_B == 32 || GJ_B == 64, "pivot block");
 
 struct GjStep {             // one per (step, subdomain); n0 == 0: the subdomain is not active in this step
   int n1, n0;               // size of the deeper level (dimension of Z_in; 0 at the subdomain's first step) and of this level
@@ -195,49 +201,159 @@ __device__ __forceinline__ const double *gj_src(const GjDom &dm, int kb) { retur
 // P = (pivot block)^{-1}: ONE wave per subdomain, lane r holds row r of the block in registers; a Gauss-Jordan step
 // broadcasts the scaled pivot row with v_readlane (no LDS round trips, no barriers in the 32-step dependency chain).
 // row[c] = lane r's row of a 32 x 32 SPD block (identity beyond the block's size) -> its inverse, in place
-__device__ __forceinline__ void gj_invert_rows(double (&row)[GJ_B], int r) {
+__device__ __forceinline__ void gj_invert_rows(double (&row)[GJ_H], int r) {
 #pragma unroll
-  for (int p = 0; p < GJ_B; ++p) {
+  for (int p = 0; p < GJ_H; ++p) {
     const double piv = 1.0 / lane_read(row[p], p);
     if (r == p) {
 #pragma unroll
-      for (int c = 0; c < GJ_B; ++c) row[c] = c == p ? piv : row[c] * piv;
+      for (int c = 0; c < GJ_H; ++c) row[c] = c == p ? piv : row[c] * piv;
     }
     const double f = row[p];
 #pragma unroll
-    for (int c = 0; c < GJ_B; ++c) {
+    for (int c = 0; c < GJ_H; ++c) {
       const double rp = lane_read(row[c], p);          // the (scaled) pivot row, uniform
       if (r != p && c != p) row[c] -= f * rp;
     }
     if (r != p) row[p] = -f * piv;
   }
 }
-// The pivot inverse of block step kb lives in P + (kb & 1) * 1024: the update launch of step kb reads it while one of its
+typedef double gj_d4 __attribute__((ext_vector_type(4)));
+// in-place inverse of the 32 x 32 SPD block at M[o.., o..] by ONE wave, all 64 lanes: lane l holds half a row (row l & 31,
+// columns 16 (l >> 5) .. + 15) in registers. A Gauss-Jordan step passes the pivot row and the pivot column through 64
+// doubles of LDS (`scr`; broadcast reads, no v_readlane chain, no second wave): ~70 instructions per step instead of
+// ~200 with whole rows per lane and 64 v_readlanes — the 32-step chain is the critical path of the whole level elimination
+// (every block step waits for it), so this is the kernel that sets the set-up's time.
+__device__ __forceinline__ void gj_inv32(double *M, int LD, int o, double *scr) {
+  if (threadIdx.x < 64) {
+    const int r = threadIdx.x & 31, h = threadIdx.x >> 5;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = M[(o + r) * LD + o + 16 * h + c];
+    double *prow = scr, *fcol = scr + 32;
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+      constexpr int dummy = 0; (void)dummy;
+      const int ph = p >> 4, pc = p & 15;
+      if (h == ph) fcol[r] = a[pc];
+      if (r == p) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) prow[16 * h + c] = a[c];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const double piv = 1.0 / prow[p];
+      const double f = fcol[r];
+      double pr[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) pr[c] = prow[16 * h + c] * piv;      // the scaled pivot row (this lane's half)
+      if (r == p) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] = pr[c];
+        if (h == ph) a[pc] = piv;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] -= f * pr[c];
+        if (h == ph) a[pc] = -f * piv;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                                  // the next step overwrites prow / fcol
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) M[(o + r) * LD + o + 16 * h + c] = a[c];
+  }
+}
+// in-place inverse of the SPD GJ_B x GJ_B block in LDS (row stride LD; identity beyond the matrix' end), 256 threads. GJ_B = 64:
+//   [A B; B' D]^{-1} = [P + Y X', -Y; -Y', S^{-1}],  P = A^{-1},  X = P B,  S = D - B' X,  Y = X S^{-1}
+// two 32-step register inversions (the serial part) and five 32 x 32 x 32 products; `W` = 32 x LD doubles of scratch, `scr` = 64 more.
+__device__ __forceinline__ void gj_invert_block(double *M, int LD, double *W, double *scr) {
+  if (GJ_B == 32) {
+    gj_inv32(M, LD, 0, scr);
+    __syncthreads();
+    return;
+  }
+  gj_inv32(M, LD, 0, scr);                                              // P = A^{-1}                        (M11)
+  __syncthreads();
+  // X = P B -> W (32 x 32)
+  {
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = l & 15, lk = l >> 4, bi = wv >> 1, bj = wv & 1;
+    gj_d4 d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 4)
+      d = __builtin_amdgcn_mfma_f64_16x16x4f64(M[(16 * bi + lc) * LD + kk + lk], M[(kk + lk) * LD + 32 + 16 * bj + lc], d, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) W[(16 * bi + lk + 4 * v) * LD + 16 * bj + lc] = d[v];
+  }
+  __syncthreads();
+  // S = D - B' X   (B' = M21 as stored: the block is symmetric; read M12 transposed)      -> M22
+  {
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = l & 15, lk = l >> 4, bi = wv >> 1, bj = wv & 1;
+    gj_d4 d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 4)
+      d = __builtin_amdgcn_mfma_f64_16x16x4f64(M[(kk + lk) * LD + 32 + 16 * bi + lc], W[(kk + lk) * LD + 16 * bj + lc], d, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) M[(32 + 16 * bi + lk + 4 * v) * LD + 32 + 16 * bj + lc] -= d[v];
+  }
+  __syncthreads();
+  gj_inv32(M, LD, 32, scr);                                             // S^{-1}                            (M22)
+  __syncthreads();
+  // Y = X S^{-1} -> M12 (B is no longer needed), then M21 = -Y', M12 = -Y, M11 = P + Y X'
+  {
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = l & 15, lk = l >> 4, bi = wv >> 1, bj = wv & 1;
+    gj_d4 d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 4)
+      d = __builtin_amdgcn_mfma_f64_16x16x4f64(W[(16 * bi + lc) * LD + kk + lk], M[(32 + kk + lk) * LD + 32 + 16 * bj + lc], d, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) M[(16 * bi + lk + 4 * v) * LD + 32 + 16 * bj + lc] = d[v];      // Y (sign below)
+  }
+  __syncthreads();
+  {
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = l & 15, lk = l >> 4, bi = wv >> 1, bj = wv & 1;
+    gj_d4 d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 4)                                   // Y X' : A = Y[i][k], B = X'[k][j] = X[j][k]
+      d = __builtin_amdgcn_mfma_f64_16x16x4f64(M[(16 * bi + lc) * LD + 32 + kk + lk], W[(16 * bj + lc) * LD + kk + lk], d, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) M[(16 * bi + lk + 4 * v) * LD + 16 * bj + lc] += d[v];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+    const int i = e >> 5, j = e & 31;
+    const double y = M[i * LD + 32 + j];
+    M[i * LD + 32 + j] = -y;
+    M[(32 + j) * LD + i] = -y;
+  }
+  __syncthreads();
+}
+// The pivot inverse of block step kb lives in P + (kb & 1) * GJ_B^2: the update launch of step kb reads it while one of its
 // workgroups writes the inverse for step kb + 1 into the other half (look-ahead, below). This kernel serves kb = 0 only.
-__global__ __launch_bounds__(64) void k_gj_pivot(int step, int kb, int ndom, const GjStep *__restrict__ steps,
-                                                 const GjDom *__restrict__ doms) {
+__global__ __launch_bounds__(256) void k_gj_pivot(int step, int kb, int ndom, const GjStep *__restrict__ steps,
+                                                  const GjDom *__restrict__ doms) {
   const GjStep st = steps[(size_t)step * ndom + blockIdx.z];
   if (kb >= st.nb) return;
   const GjDom dm = doms[blockIdx.z];
   const int n = st.n0, k0 = kb * GJ_B, bs = min(GJ_B, n - k0);
   const double *A = gj_src(dm, kb);
-  const int r = threadIdx.x & 31;                      // lanes 32..63 mirror lanes 0..31 (results of the lower half are stored)
-  double row[GJ_B];
-#pragma unroll
-  for (int c = 0; c < GJ_B; ++c) row[c] = (r < bs && c < bs) ? A[(k0 + r) + (size_t)(k0 + c) * n] : (r == c ? 1.0 : 0.0);
-  gj_invert_rows(row, r);
-  double *Pd = dm.P + (kb & 1) * (GJ_B * GJ_B);
-  if (threadIdx.x < GJ_B) {
-#pragma unroll
-    for (int c = 0; c < GJ_B; ++c) Pd[r + c * GJ_B] = row[c];                    // column-major 32 x 32
+  constexpr int LD = GJ_B + 1;
+  __shared__ double Mb[GJ_B * LD];
+  __shared__ double Wb[GJ_H * LD + 64];
+  for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) {
+    const int r = e % GJ_B, c = e / GJ_B;
+    Mb[r * LD + c] = (r < bs && c < bs) ? A[(k0 + r) + (size_t)(k0 + c) * n] : (r == c ? 1.0 : 0.0);
   }
+  __syncthreads();
+  gj_invert_block(Mb, LD, Wb, Wb + GJ_H * LD);
+  double *Pd = dm.P + (kb & 1) * (GJ_B * GJ_B);
+  for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) Pd[e] = Mb[(e % GJ_B) * LD + e / GJ_B];   // column-major GJ_B x GJ_B
 }
 // one 64 x 64 tile of the updated matrix from the previous copy, on the fp64 matrix cores (v_mfma_f64_16x16x4_f64:
 // A[l & 15][k = l >> 4], B[k = l >> 4][l & 15], D: col = l & 15, row = (l >> 4) + 4 reg). R = P A[K, J] (32 x 64) first, then
 // the trailing update computed TRANSPOSED — the instruction's row index runs over the tile's columns j, its column index
 // over the tile's rows i — so that a lane's four results sit in 16-lane groups of consecutive i: loads and stores of the
 // column-major matrix are 128-byte segments. Wave v owns rows 16 v .. 16 v + 15 of the tile.
-typedef double gj_d4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, const GjStep *__restrict__ steps,
                                                    const GjDom *__restrict__ doms) {
   const int dz = blockIdx.z;   // (the subdomain as the FASTEST grid dimension, so that every look-ahead tile is dispatched in the first round, was measured: 55.8 us per launch against 51.7 — neighbouring workgroups then work on different matrices)
@@ -267,17 +383,24 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   // read any entry.
   if (bx > by) return;
   const int i0 = bx * GJ_T, j0 = by * GJ_T;
-  // 42 KB of LDS: three workgroups per CU (with A[K, J] and R in buffers of their own, 58 KB, it was two)
-  constexpr int LDS_PM = GJ_B * (GJ_B + 1), LDS_R = GJ_B * (GJ_T + 1), LDS_CC = GJ_T * (GJ_B + 1);
+  // LDS: A[K, J] / R (GJ_B x 65) and A[I, K] (64 x (GJ_B + 1)): 33.4 KB with a 32-wide pivot block (three workgroups per CU),
+  // 66.6 KB with a 64-wide one (two). The pivot inverse P is NOT staged: every lane keeps the GJ_B / 4 entries it feeds to
+  // the matrix cores in registers (one request per entry, served by L2: every tile reads the same 32 KB).
+  constexpr int LDS_R = GJ_B * (GJ_T + 1), LDS_CC = GJ_T * (GJ_B + 1);
   static_assert(LDS_R + LDS_CC >= GJ_T * (GJ_T + 1), "the mirror image of a tile is staged in the R and Cc buffers");
-  __shared__ double lds[LDS_PM + LDS_R + LDS_CC];
-  double (&Pm)[GJ_B][GJ_B + 1] = *reinterpret_cast<double (*)[GJ_B][GJ_B + 1]>(lds);                   // P[r][c]
-  double (&R)[GJ_B][GJ_T + 1] = *reinterpret_cast<double (*)[GJ_B][GJ_T + 1]>(lds + LDS_PM);           // A[K, J] (32 x 64) first, then R = P * A[K, J], then (look-ahead tile) the next pivot block
-  double (&Cc)[GJ_T][GJ_B + 1] = *reinterpret_cast<double (*)[GJ_T][GJ_B + 1]>(lds + LDS_PM + LDS_R);  // A[I, K]           (64 x 32)
+  __shared__ double lds[LDS_R + LDS_CC];
+  double (&R)[GJ_B][GJ_T + 1] = *reinterpret_cast<double (*)[GJ_B][GJ_T + 1]>(lds);           // A[K, J] first, then R = P * A[K, J], then (look-ahead tile) the next pivot block
+  double (&Cc)[GJ_T][GJ_B + 1] = *reinterpret_cast<double (*)[GJ_T][GJ_B + 1]>(lds + LDS_R);  // A[I, K]
   double (&Ak)[GJ_B][GJ_T + 1] = R;
   const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = l & 15, lk = l >> 4;
-  const double *Pcur = dm.P + (kb & 1) * (GJ_B * GJ_B);
-  for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) Pm[e % GJ_B][e / GJ_B] = Pcur[e];
+  const double *Pcur = dm.P + (kb & 1) * (GJ_B * GJ_B);   // column-major, symmetric
+  // R = P A[K, J]: (GJ_B / 16) x 4 blocks of 16 x 16; wave wv owns t-block(s) and j-blocks as below
+  constexpr int TBW = GJ_B == 64 ? 1 : 1, NQ = GJ_B == 64 ? 4 : 2;      // blocks per wave: 4 (64: tb = wv, all j) or 2 (32: tb = wv & 1, j = 2 (wv >> 1) + q)
+  (void)TBW;
+  const int tb = GJ_B == 64 ? wv : (wv & 1), jb0 = GJ_B == 64 ? 0 : 2 * (wv >> 1);
+  double pa[GJ_B / 4];                                                   // P[16 tb + lc][kk + lk], kk = 0, 4, ...
+#pragma unroll
+  for (int q = 0; q < GJ_B / 4; ++q) pa[q] = Pcur[(16 * tb + lc) + (size_t)(4 * q + lk) * GJ_B];
   for (int e = threadIdx.x; e < GJ_B * GJ_T; e += 256) {
     const int t = e % GJ_B, c = e / GJ_B;        // A[k0 + t, j0 + c]: consecutive threads walk down a column
     Ak[t][c] = (t < bs && j0 + c < n) ? A[(k0 + t) + (size_t)(j0 + c) * n] : 0.0;
@@ -294,25 +417,33 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
       const int j = j0 + 16 * jt + lk + 4 * v;
       acc[jt][v] = (i < n && j < n) ? A[i + (size_t)j * n] : 0.0;
     }
+  // With a pivot block as wide as a tile the tiles of block column K (by == kb, above the diagonal) hold only column-panel
+  // entries -(A_iK P): the SAME matrix-core loop as the trailing update with P in place of R and a zero start
+  // (D[j][i] = Σ_u P[u][j] (-A[i][k0 + u])); the diagonal tile (kb, kb) becomes P itself.
+  const bool kcol = GJ_B == GJ_T && by == kb;
   __syncthreads();
-  {  // R = Pm * Ak: 2 x 4 blocks of 16 x 16, two per wave (t-block = wv & 1, j-blocks 2 (wv >> 1) and + 1)
-    const int tb = wv & 1;
-    gj_d4 d[2];
+  if (!kcol) {
+    gj_d4 d[NQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int jbk = 2 * (wv >> 1) + q;
+    for (int q = 0; q < NQ; ++q) {
+      const int jbk = jb0 + q;
       d[q] = gj_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int kk = 0; kk < GJ_B; kk += 4)
-        d[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[16 * tb + lc][kk + lk], Ak[kk + lk][16 * jbk + lc], d[q], 0, 0, 0);
+        d[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kk / 4], Ak[kk + lk][16 * jbk + lc], d[q], 0, 0, 0);
     }
     __syncthreads();                             // every wave has read A[K, J]: the buffer becomes R
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int jbk = 2 * (wv >> 1) + q;
+    for (int q = 0; q < NQ; ++q) {
+      const int jbk = jb0 + q;
 #pragma unroll
       for (int v = 0; v < 4; ++v) R[16 * tb + lk + 4 * v][16 * jbk + lc] = d[q][v];
     }
+  } else {
+    __syncthreads();
+    for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) R[e % GJ_B][e / GJ_B] = Pcur[e];   // P[u][jl] (columns beyond bs: identity, times a zero panel)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) acc[jt] = gj_d4{0.0, 0.0, 0.0, 0.0};
   }
   __syncthreads();
   // acc[jt] (rows j, cols i) -= R[K, J_jt]' * Cc[I, K]'  ==  (A_ij - A_iK (P A_Kj))'
@@ -331,20 +462,20 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
       const int jl = 16 * jt + lk + 4 * v, j = j0 + jl;
       if (i >= n || j >= n) continue;
       const bool jk = j >= k0 && j < k0 + bs;
-      double val = acc[jt][v];                                                 // A_ij - A_iK (P A_Kj)
-      if (ik && jk) val = Pm[i - k0][j - k0];
+      double val = acc[jt][v];                                                 // A_ij - A_iK (P A_Kj);  block column K: -(A_iK P)[i, j - k0]
+      if (ik && jk) val = Pcur[(i - k0) + (size_t)(j - k0) * GJ_B];
       else if (ik) val = R[i - k0][jl];                                        // (P A_Kj)[i - k0, j]
-      else if (jk) {                                                           // -(A_iK P)[i, j - k0]
+      else if (jk && !kcol) {                                                  // -(A_iK P)[i, j - k0]   (32-wide pivot block inside a 64-wide tile)
         double s2 = 0.0;
-        for (int u = 0; u < GJ_B; ++u) s2 += Cc[16 * wv + lc][u] * Pm[u][j - k0];
+        for (int u = 0; u < GJ_B; ++u) s2 += Cc[16 * wv + lc][u] * Pcur[u + (size_t)(j - k0) * GJ_B];
         val = -s2;
       }
       O[i + (size_t)j * n] = val;
       acc[jt][v] = val;
     }
   if (bx != by) {                                // the mirror image: M[j,i] = σ'(i) σ'(j) M[i,j], σ' = -1 below k1 (swept after this step)
-    __syncthreads();                             // R, Cc, Pm are read for the last time above
-    double *T = lds + LDS_PM;                    // [GJ_T][GJ_T + 1]
+    __syncthreads();                             // R, Cc are read for the last time above
+    double *T = lds;                             // [GJ_T][GJ_T + 1]
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
@@ -365,7 +496,11 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
     return;
   }
   if (!special) return;
-  __syncthreads();                               // R is read for the last time above: it becomes the landing zone of the next pivot block
+  // Look-ahead: this diagonal tile holds the next pivot block (rows / columns k1 .. k1 + bs1 of the updated matrix); its inverse
+  // goes to the other half of P. R becomes the landing zone (row stride GJ_T + 1), Cc the scratch of the block inversion.
+  __syncthreads();
+  for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) { const int rr = e / GJ_B, cc = e % GJ_B; R[rr][cc] = rr == cc ? 1.0 : 0.0; }   // identity beyond the matrix' end
+  __syncthreads();
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
@@ -374,18 +509,10 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
       if (i >= k1 && i < k1 + bs1 && j >= k1 && j < k1 + bs1) R[i - k1][j - k1] = acc[jt][v];   // (trailing entries: K1 != K)
     }
   __syncthreads();
-  if (threadIdx.x < 64) {                        // one wave: the same register-resident inversion as k_gj_pivot
-    const int r = threadIdx.x & 31;
-    double row[GJ_B];
-#pragma unroll
-    for (int c = 0; c < GJ_B; ++c) row[c] = (r < bs1 && c < bs1) ? R[r][c] : (r == c ? 1.0 : 0.0);
-    gj_invert_rows(row, r);
-    double *Pn = dm.P + ((kb + 1) & 1) * (GJ_B * GJ_B);
-    if (threadIdx.x < GJ_B) {
-#pragma unroll
-      for (int c = 0; c < GJ_B; ++c) Pn[r + c * GJ_B] = row[c];
-    }
-  }
+  static_assert(LDS_CC >= GJ_H * (GJ_T + 1) + 64 || GJ_B == 32, "scratch of the block inversion lives in the Cc buffer");
+  gj_invert_block(&R[0][0], GJ_T + 1, &Cc[0][0], &Cc[0][0] + (GJ_B == 32 ? 0 : GJ_H * (GJ_T + 1)));
+  double *Pn = dm.P + ((kb + 1) & 1) * (GJ_B * GJ_B);
+  for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) Pn[e] = R[e % GJ_B][e / GJ_B];
 }
 // ---- the end of a subdomain's chain: S (upper triangle mirrored) = A_ΓΓ - B' Z_0 B; w = B' (Z_0 g_0)
 __global__ __launch_bounds__(256) void k_gj_final_pick(int ndom, const GjDom *__restrict__ doms, const int *__restrict__ c_ptr,
@@ -599,7 +726,7 @@ inline void gj_enqueue(mi_setup_s &P, hipStream_t s, const double *ii, const dou
     hipLaunchKernelGGL(k_gj_scatter, dim3(8, 1, nd), dim3(256), 0, s, step, nd, st, dm, P.src.p, P.dst.p, ii);
     if (bI) hipLaunchKernelGGL(k_gj_g, dim3(cdiv(nm, 256), 1, nd), dim3(256), 0, s, step, nd, st, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ii, P.perm.p, bI);
     for (int kb = 0; kb < G.nb_step[step]; ++kb) {
-      if (kb == 0) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nd), dim3(64), 0, s, step, kb, nd, st, dm);   // later pivots: look-ahead in the update
+      if (kb == 0) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nd), dim3(256), 0, s, step, kb, nd, st, dm);   // later pivots: look-ahead in the update
       hipLaunchKernelGGL(k_gj_update, dim3(cdiv(nm, GJ_T), cdiv(nm, GJ_T), nd), dim3(256), 0, s, step, kb, nd, st, dm);
     }
     if (G.keep) hipLaunchKernelGGL(k_gj_keep, dim3(std::min(1024, cdiv(nm * nm, 1024)), 1, nd), dim3(256), 0, s, step, nd, st, dm, G.zstore.p);
@@ -820,7 +947,7 @@ inline void pinv_blocks_fast(mi_ctx_s *c, int ndom, const int64_t *n_gamma_d, co
     std_.upload(sb, s); dmd.upload(db, s);
     const int nb_ = (int)ds.size();
     for (int kb = 0; kb < nbmax; ++kb) {
-      if (kb == 0) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nb_), dim3(64), 0, s, 0, kb, nb_, std_.p, dmd.p);   // later pivots: look-ahead in the update
+      if (kb == 0) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nb_), dim3(256), 0, s, 0, kb, nb_, std_.p, dmd.p);   // later pivots: look-ahead in the update
       hipLaunchKernelGGL(k_gj_update, dim3(cdiv(nmax, GJ_T), cdiv(nmax, GJ_T), nb_), dim3(256), 0, s, 0, kb, nb_, std_.p, dmd.p);
     }
     for (size_t k = 0; k < ds.size(); ++k) {

@@ -48,6 +48,19 @@ def kernel_us(api, ctx, op, x, reps):
     return min(op.time_dominant(x, reps) for _ in range(3))
 
 
+def profiled_kernel_us(csv_name, kernel):
+    """Average duration (us) of `kernel` in a committed rocprofv3 kernel-stats summary (profiles/), or None."""
+    try:
+        import csv
+        with open(os.path.join(ROOT, "profiles", csv_name)) as fh:
+            for r in csv.DictReader(fh):
+                if kernel in r["Name"]:
+                    return float(r["AverageNs"]) / 1e3
+    except Exception:
+        pass
+    return None
+
+
 def spmv_traffic():
     """PMC HBM-side bytes per launch of the CSR SpMV at config 2, if a profile has been committed."""
     try:
@@ -216,7 +229,13 @@ def config2_entry(args, api, fem, ctx, entry, torch):
           lambda: api.pcg(Aop, bd, zf(), Mj, maxit=100, eps=args.eps), 100, spmv_bytes + 120 * n,
           {"workload": f"configs[1]: N=500, n={n}, nnz={A.nnz}, pcg(A,b,0,Jacobi)",
            "spmv_replayed_us": round(us, 3), "spmv_bytes": int(spmv_bytes),
-           "spmv_replayed_frac": round(spmv_bytes / us / 1e3 / HBM_PEAK_GBS, 4)})
+           "spmv_replayed_frac": round(spmv_bytes / us / 1e3 / HBM_PEAK_GBS, 4),
+           # what the SOLVER runs is k_spmv_pcg (SpMV of the direction formed on the fly + beta, stop rule, p, p'Ap), not the bare
+           # replayed SpMV above: its own kernel time from the committed rocprofv3 summary of this workload
+           "spmv_in_loop": (lambda t: None if t is None else {"kernel": "k_spmv_pcg", "us": round(t, 2),
+                                                              "frac_of_spmv_bytes": round(spmv_bytes / t / 1e3 / HBM_PEAK_GBS, 4),
+                                                              "source": "profiles/r03_kernel_stats_fullA.csv (rocprofv3 --kernel-trace --stats of `bench.py --workload fullA`)"})(
+               profiled_kernel_us("r03_kernel_stats_fullA.csv", "k_spmv_pcg"))})
 
 
 def many_subdomains_entry(args, api, fem, ctx, entry, torch, out, t_all):
@@ -603,8 +622,10 @@ def main():
                 ctx.peer_ready()
             elif args.exchange == "peer":
                 raise SystemExit("--exchange peer: the peer exchange could not be set up on every rank")
-        if peer_on and world > 1:
+        if peer_on and (world > 1 or args.force_dist):
             args.shard_precond = True      # both operators sharded: two cheap exchanges per iteration instead of a replicated ΠS stream
+                                           # (--force-dist on one GPU: the whole sharded machinery with every tile active — what the
+                                           # two exchanges of an iteration cost when the arenas are local memory)
         bs = torch.from_numpy(P.b_schur).cuda()
         dist.all_reduce(bs)                                     # b_schur = Σ_ranks (set-up plumbing)
         b_host = bs.cpu().numpy()
@@ -614,7 +635,7 @@ def main():
         os.environ["MI355_FORCE_REDUCE"] = "1"   # one-rank rehearsal: keep the collectives of the sharded S
     S = api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(lo, hi))
     if not args.shard_precond:
-        os.environ.pop("MI355_FORCE_REDUCE", None)
+        os.environ.pop("MI355_FORCE_REDUCE", None)        # (kept for the Neumann-Neumann blocks when they are "sharded" too)
     if multi and not args.shard_precond:
         # S is sharded (subdomain d on GPU d, one all-reduce per S-apply). The Neumann-Neumann blocks are replicated
         # on every rank instead (68 MB): the NN-apply is then purely local and an iteration needs ONE all-reduce.

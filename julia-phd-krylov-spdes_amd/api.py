@@ -133,6 +133,28 @@ class Context:
         for t in ts:
             t.record_stream(ext)
 
+    def _order(self, tensors, after: bool) -> None:
+        """The Python operators that hand torch tensors back (`A * x`, `schur_rhs`, `interior_solutions`) behave like torch
+        ops: the context's stream waits for torch's current stream before the call, torch's current stream waits for the
+        context's after it (two events, no host synchronisation), and the allocator is told (`_record`). The bare C entry
+        points keep the contract of INTEGRATION.md: ordering is the caller's."""
+        ts = [t for t in tensors if t is not None and _is_torch(t) and t.is_cuda]
+        if not ts:
+            return
+        import torch
+        sp = vp()
+        check(self._L.mi_ctx_get_stream(self._h, C.byref(sp)))
+        cur = torch.cuda.current_stream(ts[0].device)
+        if not sp.value or cur.cuda_stream == sp.value:
+            return
+        ext = torch.cuda.ExternalStream(sp.value, device=ts[0].device)
+        if after:
+            cur.wait_stream(ext)
+            for t in ts:
+                t.record_stream(ext)
+        else:
+            ext.wait_stream(cur)
+
     def synchronize(self) -> None:
         check(self._L.mi_ctx_synchronize(self._h))
 
@@ -306,7 +328,9 @@ class Operator:
             else:
                 out = np.empty(self.n)
         ko, po = self.ctx._ptr(out, self.n, writable=True)
+        self.ctx._order((kx, ko), after=False)
         check(self.ctx._L.mi_op_apply(self._h, px, po))
+        self.ctx._order((kx, ko), after=True)
         return ko
 
     __call__ = apply
@@ -523,7 +547,9 @@ class MatrixFreeLocalSchurs(Operator):
         else:
             out = np.empty(self.n)
             po = vp(out.ctypes.data)
+        self.ctx._order((k1, k2, out), after=False)
         check(self.ctx._L.mi_schur_matfree_rhs(self._h, p1, p2, po))
+        self.ctx._order((k1, k2, out), after=True)
         return out
 
 
@@ -540,7 +566,9 @@ def _interior_solutions(self, u_Γ, b_I):
     else:
         out = np.empty(np.asarray(b_I).size)
         po = vp(out.ctypes.data)
+    self.ctx._order((k1, k2, out), after=False)
     check(self.ctx._L.mi_schur_matfree_interior_solutions(self._h, p1, p2, po))
+    self.ctx._order((k1, k2, out), after=True)
     return out
 
 

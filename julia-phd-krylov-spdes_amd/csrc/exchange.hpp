@@ -37,6 +37,7 @@ struct XchgState {            // device resident, one per context
   int err_rank;               // ... waiting for this rank
   unsigned long long err_epoch, err_seen;  // ... at this exchange; the flag stood at err_seen
   int *abort_done;            // the running solve's stop flag (or null): an expired wait ends the loop instead of iterating on garbage
+  unsigned int arrived;       // workgroups of the running table exchange that have published their stores
 };
 struct XchgPeers {            // by-value kernel argument
   int n, rank;
@@ -74,33 +75,46 @@ __device__ __forceinline__ void xchg_wait(XchgState *st, const XchgPeers &P, uns
   }
 }
 
-// ---- table exchange: this rank's entries of `src` (list own_idx) into copy (e & 1) of the table in EVERY arena, signal, wait.
-// One workgroup: the entries are a few thousand doubles; the kernel is the whole exchange (one launch).
+// ---- table exchange: this rank's entries of `src` (list own_idx, ascending) into copy (e & 1) of the table in EVERY arena,
+// signal, wait. One launch of (chunks × destinations) workgroups: workgroup (c, q) stores chunk c of the entries into
+// arena q — the stores are 8-byte scatters (slots of 32-byte rows), one workgroup issues about 1.4 of them per ns
+// (tools/probes/xchg_probe.hip), and there are n_own × n ≈ the whole table of them whatever the number of ranks. Each
+// workgroup publishes its stores (barrier, then ONE system-scope fence: 16 waves fencing cost 4 µs more, same probe)
+// and counts itself in; the last one to arrive signals the flags and waits for the peers'.
+constexpr int XCHG_PUSH_CHUNK = 4096;
 __global__ __launch_bounds__(1024) void k_xchg_push(XchgPeers P, XchgState *st, size_t table_off, size_t copy_doubles,
                                                     const double *__restrict__ src, const int *__restrict__ own_idx, int n_own,
                                                     const int *done) {
   if (done && *done) return;
   __shared__ unsigned long long e_sh;
-  const unsigned long long e_next = st->epoch + 1;
+  __shared__ int last_sh;
+  const unsigned long long e_next = st->epoch + 1;       // (the last arriver advances it, after every workgroup has read it)
   const size_t par = (size_t)(e_next & 1) * copy_doubles;
-  for (int i0 = threadIdx.x; i0 < n_own; i0 += 4 * 1024) {
+  {
+    double *dst = reinterpret_cast<double *>(P.arena[blockIdx.y] + table_off) + par;
+    const int i0 = blockIdx.x * XCHG_PUSH_CHUNK + threadIdx.x;
     int id[4];
     double v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int i = i0 + k * 1024; id[k] = i < n_own ? own_idx[i] : -1; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = id[k] >= 0 ? src[id[k]] : 0.0;
-    for (int q = 0; q < P.n; ++q) {
-      double *dst = reinterpret_cast<double *>(P.arena[q] + table_off) + par;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) if (id[k] >= 0) dst[id[k]] = v[k];
+    for (int k = 0; k < 4; ++k) if (id[k] >= 0) dst[id[k]] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    const unsigned int total = gridDim.x * gridDim.y;
+    const unsigned int prev = total > 1 ? __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    last_sh = prev == total - 1;
+    if (last_sh) {
+      __hip_atomic_store(&st->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      e_sh = xchg_signal(st, P);
     }
   }
-  __threadfence_system();
   __syncthreads();
-  if (threadIdx.x == 0) e_sh = xchg_signal(st, P);
-  __syncthreads();
-  if (threadIdx.x < 64) xchg_wait(st, P, e_sh);
+  if (last_sh && threadIdx.x < 64) xchg_wait(st, P, e_sh);
 }
 
 // ---- generic all-reduce (sum) through per-rank staging slots [2][n_ranks][cap] in every arena: copy, signal + wait, sum
@@ -241,7 +255,8 @@ struct PeerComm {
   }
   void push(size_t table_off, size_t copy_doubles, const double *src, const int *own_idx, int n_own, hipStream_t s, const int *done) {
     if (!ready) raise(MI_ERR_COMM, "peer exchange used before every arena was imported");
-    hipLaunchKernelGGL(k_xchg_push, dim3(1), dim3(1024), 0, s, peers, st, table_off, copy_doubles, src, own_idx, n_own, done);
+    const int chunks = std::max(1, (n_own + XCHG_PUSH_CHUNK - 1) / XCHG_PUSH_CHUNK);   // (a rank without entries still signals and waits)
+    hipLaunchKernelGGL(k_xchg_push, dim3(chunks, n), dim3(1024), 0, s, peers, st, table_off, copy_doubles, src, own_idx, n_own, done);
     MI_HIP(hipGetLastError());
   }
   // 0, or 1 when a wait has expired since the last call (cleared); synchronises the stream

@@ -292,6 +292,10 @@ __global__ __launch_bounds__(NT, 8) void k_spmv_pcg(int nblocks, const SpmvBlock
   const long long it0 = st->it, maxit = st->maxit, cap = st->res_cap;
   const double tol = st->tol, old = precond ? st->rTz_prev : st->rTr_prev;
   asm volatile("" ::"s"(bi.r0), "s"(bi.r1), "s"(bi.k0), "s"(bi.k1), "s"(done0), "s"(it0), "s"(maxit), "s"(cap), "s"(tol), "s"(old));
+  // the partial sums of the previous launch are requested FIRST (they need no index): results return in issue order, so the
+  // reduction to beta below waits for these two loads only while the non-zeros and their gathered pairs are still in flight
+  double rr = (int)threadIdx.x < g_vec ? part_rr[threadIdx.x] : 0.0;
+  double rz = (precond && (int)threadIdx.x < g_vec) ? part_rz[threadIdx.x] : 0.0;
   if (done0) return;
   const int r0 = has ? bi.r0 : 0, r1 = has ? bi.r1 : 0, k0 = has ? bi.k0 : 0, nnz = has ? bi.k1 - bi.k0 : 0;
   const double2 *pz_old = reinterpret_cast<const double2 *>((it0 & 1) ? pz1 : pz0);
@@ -312,9 +316,7 @@ __global__ __launch_bounds__(NT, 8) void k_spmv_pcg(int nblocks, const SpmvBlock
   int a0 = 0, e0 = 0;
   double2 o0 = make_double2(0.0, 0.0);
   if (ra < r1) { a0 = rowptr[ra] - k0; e0 = rowptr[ra + 1] - k0; o0 = pz_old[ra]; }
-  // ---- scalars (identical in every workgroup): g_vec <= NT partials per sum, one load per thread, one barrier for both
-  double rr = (int)threadIdx.x < g_vec ? part_rr[threadIdx.x] : 0.0;
-  double rz = (precond && (int)threadIdx.x < g_vec) ? part_rz[threadIdx.x] : 0.0;
+  // ---- scalars (identical in every workgroup): g_vec <= NT partials per sum, one load per thread (above), one barrier for both
   __shared__ double sm2[2 * (NT / 64)];
   block_sum2_t<NT>(rr, rz, sm2);
   if (!precond) rz = rr;
@@ -394,7 +396,12 @@ __global__ __launch_bounds__(NT) void k_update_xr_blk(const int *__restrict__ xc
   const int lo = (int)(R0 + (R1 - R0) * j / nj), hi = (int)(R0 + (R1 - R0) * (j + 1) / nj);
   const double num = precond ? rTz0 : rTr0;
   double2 *pz = reinterpret_cast<double2 *>((it_n & 1) ? pz1 : pz0);     // the pairs k_spmv_pcg has just written p into
-  // the first four rows of this thread: loads ahead of the reduction
+  // the partial sums of p'Ap first (up to eight per thread in flight; more in the loop below), then the first four rows of this
+  // thread: everything is requested ahead of the reduction, and the reduction waits for the partials only
+  double dpart = 0.0;
+  double t8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { const int i = (int)threadIdx.x + k * NT; t8[k] = i < nblocks ? part_pAp[i] : 0.0; }
   double pv[4], av[4], xv[4], rv[4], dv[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -403,7 +410,16 @@ __global__ __launch_bounds__(NT) void k_update_xr_blk(const int *__restrict__ xc
     pv[k] = ok ? pz[rw].x : 0.0; av[k] = ok ? Ap[rw] : 0.0; xv[k] = ok ? x[rw] : 0.0; rv[k] = ok ? r[rw] : 0.0;
     dv[k] = ok && diag == 2 ? dinv[rw] : 1.0;
   }
-  const double d = sum_partials(part_pAp, nblocks, sm);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dpart += t8[k];                            // (the order sum_partials uses: bit-identical alpha)
+  for (int i0 = (int)threadIdx.x + 8 * NT; i0 < nblocks; i0 += 8 * NT) {
+    double u8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u8[k] = i0 + k * NT < nblocks ? part_pAp[i0 + k * NT] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dpart += u8[k];
+  }
+  const double d = block_sum(dpart, sm);
   const double alpha = num / d;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->d = d; st->alpha = alpha;
@@ -833,7 +849,8 @@ struct GemvTile {
   long long mat_off;  // element offset of the subdomain block
   int n, ld;          // n_Γd and padded leading dimension
   int loc_off, row0;  // offset of the block in the local index space, first row of this tile
-  int active, nrows;  // active 0: the block of this subdomain lives on another rank (multi-GPU): nothing to stream here.
+  int active, nrows;  // active 0: the block of this subdomain lives on another rank (multi-GPU): nothing to stream here;
+                      // otherwise 1 + the slot of this tile's partial dot products in the folded launches.
                       // nrows: rows [row0, row0 + nrows) whose owner duties this tile performs in the folded launches
                       // (active: the WAVES*RPW streamed rows; inactive: up to one row per thread)
 };
@@ -1116,7 +1133,6 @@ struct PcgFold {
   const int *peer;          // [nloc*W] local positions of the same Γ node in the sharing subdomains (-1 pad)
   const int *jrank;         // [nloc] rank of this subdomain among the contributors of the node (0 = owner)
   int W;
-  int part_rows;            // this launch is sharded over ranks: partial dots per ROW (local order, nloc entries) instead of per tile
   // inputs that come out of a peer exchange (exchange.hpp) are double-buffered by the parity of the exchange number:
   // con_in / part_in0 / part_in1 point at copy 0, copy (*in_epoch & 1) is in_stride doubles further
   const unsigned long long *in_epoch;
@@ -1377,16 +1393,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   if (PHASE == 1 && o_q >= 0 && o_own) f.x[o_g] = o_x + coef * o_a;  // x + alpha*p (cg.jl:97), off the critical path
   __syncthreads();
   MI_FSTAMP(5);   // results scattered
-  if (f.part_rows) {
-    // multi-GPU, sharded launch: one product per ROW at its local position instead of one partial per tile — a layout that
-    // does not depend on how each rank tiles its blocks, so the ranks' arrays are a disjoint union of the full one
-    if (threadIdx.x < NR && t.row0 + (int)threadIdx.x < n) {
-      const int lr = off + t.row0 + (int)threadIdx.x;
-      if (PHASE == 0) f.part_out0[lr] = rowc1[threadIdx.x];                                   // p_g * Ap-contribution
-      else { f.part_out1[lr] = rowc1[threadIdx.x]; f.part_out0[lr] = rowc0[threadIdx.x]; }    // r_g * z-contribution; r_g^2 (owner rows)
-    }
-    return;
-  }
   if (PHASE == 1 && f.nvec > 0 && (int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + f.nvec) {
     // per-tile partial of WtA*z (defcg.jl:301): sum over this tile's rows of WtA[v, g(row)] * (z-contribution of the row);
     // the second wave does it while the first one reduces the dot products (nvec <= 64)
@@ -1409,8 +1415,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     a = wave_sum(a);
     b = wave_sum(b);
     if (threadIdx.x == 0) {
-      if (PHASE == 1) { f.part_out1[blockIdx.x] = a; f.part_out0[blockIdx.x] = b; }
-      else f.part_out0[blockIdx.x] = a;
+      const int ps = t.active - 1;   // the tile number on one GPU; a tiling-independent slot when the launch is sharded over ranks
+      if (PHASE == 1) { f.part_out1[ps] = a; f.part_out0[ps] = b; }
+      else f.part_out0[ps] = a;
     }
   }
   MI_FSTAMP(6);

@@ -27,6 +27,7 @@ inline int to_i32(int64_t v, int64_t lo, int64_t hi, const char *what) {
 }
 
 // ------------------------------------------------------------------ base class
+constexpr int PART_ROWS = 4;   // fewest rows a streamed tile can have (4 waves x 1 row)
 struct DenseBlockOp;
 struct Operator {
   mi_ctx_s *ctx;
@@ -334,6 +335,7 @@ struct DenseBlockOp : Operator {
   // r/p current+next copies
   DevBuf<double> fold_pack, fold_pack_all, fold_part1, fold_vec;
   size_t fold_con_n = 0, fold_pack_n = 0;
+  int part_total = 0;             // slots of one partial-dot array (see the tile records)
   size_t fold_p1_off = 0;         // sharded Neumann-Neumann blocks: the second partial array (r'z) sits in the pack too
   // Peer exchange (exchange.hpp): the reduced pack is a double-buffered table at offset xt_off of every rank's arena;
   // own_idx lists the pack entries this rank's launches produce (contribution slots and per-row partials of its rows).
@@ -391,6 +393,8 @@ struct DenseBlockOp : Operator {
     std::vector<long long> moff;
     std::vector<int> ldv;
     std::vector<GemvTile> tv;
+    const bool sharded_parts = reduce_over_ranks && full_maps;
+    part_total = 0;
     long long tot = 0;
     auto owned = [&](int dl) { return m0 + dl >= d0 && m0 + dl < d1; };
     for (int dl = 0; dl < maps.ndl; ++dl) {
@@ -406,14 +410,22 @@ struct DenseBlockOp : Operator {
       max_ld = std::max(max_ld, l);
       // tiles of another rank's block only do owner duties in the folded launches: as few workgroups as possible
       const int step = own ? waves * rpw : 64 * waves;
-      for (int r = 0; r < n_d; r += step)
-        tv.push_back(GemvTile{own ? tot : 0, n_d, l, maps.loc_off[dl], r, own ? 1 : 0, std::min(step, n_d - r)});
+      // `active` of a streamed tile = 1 + the slot of its partial dot products. One GPU: the tile number. Sharded over ranks:
+      // a layout every rank derives from the maps alone, whatever tiling each rank chose for its own blocks — subdomain
+      // after subdomain, one slot per PART_ROWS rows (no tiling has fewer rows per tile), so the ranks' arrays are a
+      // disjoint union of one array and the exchange adds nothing.
+      for (int r = 0; r < n_d; r += step) {
+        const int slot = sharded_parts ? part_total + r / PART_ROWS : (int)tv.size();
+        tv.push_back(GemvTile{own ? tot : 0, n_d, l, maps.loc_off[dl], r, own ? slot + 1 : 0, std::min(step, n_d - r)});
+      }
+      if (sharded_parts) part_total += (n_d + PART_ROWS - 1) / PART_ROWS;
       if (own) {
         tot += (long long)n_d * l;
         alg_bytes += 8ll * n_d * n_d + 16ll * n_d + 4ll * n_d;
       }
     }
     ntiles = (int)tv.size();
+    if (!sharded_parts) part_total = ntiles;
     moff_h = moff; ld_h = ldv;
     for (int dl = 0; dl < maps.ndl; ++dl) owned_h.push_back(owned(dl) ? 1 : 0);
     // (+ one zeroed panel behind the last block: the persistent kernel reads whole 128-double groups of a row without
@@ -447,9 +459,9 @@ struct DenseBlockOp : Operator {
     yslots_all.zero(c->stream);
     // contributions and first partial-dot array share one buffer: the sharded S launch all-reduces both in one call
     fold_con_n = (size_t)maps.nloc * maps.slot_width + 4;
-    const size_t part_n = std::max<size_t>((size_t)ntiles + 1, (size_t)maps.nloc + 1);    // per-tile, or per-row when sharded
+    const size_t part_n = (size_t)part_total + 1;
     fold_pack_n = fold_con_n + part_n;
-    if (reduce_over_ranks && full_maps && scale) { fold_p1_off = fold_pack_n; fold_pack_n += (size_t)maps.nloc + 1; }  // r'z per row, exchanged with the rest
+    if (sharded_parts && scale) { fold_p1_off = fold_pack_n; fold_pack_n += part_n; }  // partial r'z, exchanged with the rest
     fold_pack.alloc(fold_pack_n); fold_pack.zero(c->stream);
     fold_pack_all.alloc(fold_pack_n); fold_pack_all.zero(c->stream);
     fold_part1.alloc((size_t)ntiles + 1); fold_part1.zero(c->stream);
@@ -466,10 +478,14 @@ struct DenseBlockOp : Operator {
           for (int l = 0; l < maps.nd[dl]; ++l) {
             const int loc = maps.loc_off[dl] + l;
             for (int k = 0; k < W; ++k) { const int tg = maps.tgt_h[(size_t)loc * W + k]; if (tg >= 0) own.push_back(tg); }
-            own.push_back((int)fold_con_n + loc);
-            if (fold_p1_off) own.push_back((int)fold_p1_off + loc);
           }
         }
+        for (const GemvTile &t : tv)
+          if (t.active) {
+            own.push_back((int)fold_con_n + t.active - 1);
+            if (fold_p1_off) own.push_back((int)fold_p1_off + t.active - 1);
+          }
+        std::sort(own.begin(), own.end());   // neighbouring threads store neighbouring slots
         n_own = (int)own.size();
         own_idx.upload(own, c->stream);
         xt_copy = (fold_pack_n + 31) & ~(size_t)31;

@@ -334,7 +334,6 @@ struct Krylov {
     f.r_cur = Ad->fold_vec.p; f.r_nxt = f.r_cur + nl; f.p_cur = f.r_nxt + nl; f.p_nxt = f.p_cur + nl;
     f.tgt = Ad->maps.tgt.p; f.peer = Ad->maps.peer.p; f.jrank = Ad->maps.jrank.p;
     // partial-dot arrays of the OTHER operator's launch (tilings may differ); a sharded S writes one product per row
-    f.part_rows = (phase ? Md->reduce_over_ranks : Ad->reduce_over_ranks) ? 1 : 0;   // layout of THIS launch's partial dots
     f.nvec = nvec; f.n_gamma = n;
     if (nvec > 0) { f.AW = ws.AW.p; f.part_mu = ws.fold_mu.p; f.wm_loc = ws.fold_wm.p; }
     if (capture_whole && phase == 0) { f.exit_args = ws.args_dev.p; f.exit_flags = &ws.flags[0]; }
@@ -342,7 +341,7 @@ struct Krylov {
     // a sharded launch's outputs are exchanged over the ranks before the other launch reads them (reduced copy of the pack;
     // with the peer exchange a double-buffered table whose parity the reading launch takes from the exchange counter)
     const bool redA = Ad->reduce_over_ranks, redM = Md->reduce_over_ranks;
-    f.n_in = phase ? (redA ? Ad->maps.nloc : Ad->ntiles) : (redM ? Md->maps.nloc : Md->ntiles);
+    f.n_in = phase ? Ad->part_total : Md->part_total;
     if (phase) {  // ΠS launch: reads S contributions + partial p'Ap, writes ΠS contributions + partial r'r, r'z
       f.con_in = Ad->fold_con(redA); f.con_out = Md->fold_con();
       f.part_in0 = Ad->fold_part0(redA); f.part_in1 = nullptr;

@@ -117,21 +117,12 @@ class Context:
 
     def _record(self, *tensors) -> None:
         """Asynchronous entry points (`mi_dense_set_blocks`, `mi_schur_setup_run`, `mi_nn_pinv`, `mi_assembly_run` in
-        device-pointer mode) return while the context's stream still reads / writes the caller's torch tensors. Tell
-        torch's caching allocator: a tensor that dies right after the call is not handed out again before the stream has
-        passed this point (contract: INTEGRATION.md "device pointers"; the ORDER between torch's stream and the
-        context's stream is the caller's: `use_torch_stream()` or a synchronisation)."""
-        ts = [t for t in tensors if t is not None and _is_torch(t) and t.is_cuda]
-        if not ts:
-            return
-        import torch
-        sp = vp()
-        check(self._L.mi_ctx_get_stream(self._h, C.byref(sp)))
-        if not sp.value:
-            return
-        ext = torch.cuda.ExternalStream(sp.value, device=ts[0].device)
-        for t in ts:
-            t.record_stream(ext)
+        device-pointer mode) return while the context's stream still reads / writes the caller's torch tensors. Torch's
+        current stream is made to wait for the context's stream at this point (an event, no host synchronisation), so a
+        tensor that dies right after the call is not handed out again — on torch's stream — before the work is done.
+        (Not `Tensor.record_stream`: the allocator would record an event on the context's stream when the tensor is freed,
+        possibly after the context — and its stream — are gone.) Contract: INTEGRATION.md "device pointers"."""
+        self._order(tensors, after=True)
 
     def _order(self, tensors, after: bool) -> None:
         """The Python operators that hand torch tensors back (`A * x`, `schur_rhs`, `interior_solutions`) behave like torch
@@ -150,8 +141,6 @@ class Context:
         ext = torch.cuda.ExternalStream(sp.value, device=ts[0].device)
         if after:
             cur.wait_stream(ext)
-            for t in ts:
-                t.record_stream(ext)
         else:
             ext.wait_stream(cur)
 

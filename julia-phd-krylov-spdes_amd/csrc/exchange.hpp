@@ -24,30 +24,10 @@
 #include <chrono>
 
 #include "common.hpp"
+#include "exchange_dev.hpp"
 
 namespace mi {
 
-constexpr int XCHG_MAX_RANKS = 16;
-constexpr int XCHG_FLAG_STRIDE = 16;                                  // unsigned long long per flag: a 128-byte line each
-constexpr size_t XCHG_FLAG_BYTES = XCHG_MAX_RANKS * XCHG_FLAG_STRIDE * 8;  // flags at offset 0 of every arena
-
-struct XchgState {            // device resident, one per context
-  unsigned long long epoch;   // exchanges this rank has signalled
-  int err;                    // a bounded wait expired
-  int err_rank;               // ... waiting for this rank
-  unsigned long long err_epoch, err_seen;  // ... at this exchange; the flag stood at err_seen
-  int *abort_done;            // the running solve's stop flag (or null): an expired wait ends the loop instead of iterating on garbage
-  unsigned int arrived;       // workgroups of the running table exchange that have published their stores
-};
-struct XchgPeers {            // by-value kernel argument
-  int n, rank;
-  long long timeout;          // wall-clock ticks (100 MHz) a wait may take
-  char *arena[XCHG_MAX_RANKS];
-};
-
-__device__ __forceinline__ unsigned long long *xchg_flag(const XchgPeers &P, int arena_of, int flag_of) {
-  return reinterpret_cast<unsigned long long *>(P.arena[arena_of]) + (size_t)flag_of * XCHG_FLAG_STRIDE;
-}
 // thread 0 of a workgroup whose stores are all behind a system-scope fence and a barrier: next exchange number to all peers
 __device__ __forceinline__ unsigned long long xchg_signal(XchgState *st, const XchgPeers &P) {
   const unsigned long long e = st->epoch + 1;
@@ -154,6 +134,22 @@ __global__ __launch_bounds__(256) void k_xchg_settle(const XchgState *st, const 
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
+// the wait half of an exchange whose stores and flags came out of the producing launch itself (k_gemv_pcg): one wave
+// (4.8 us with the stop flag, the counter, the error word and the flag read one after the other; all four are requested at
+// once here and the clock is only read when a flag is not there yet)
+__global__ __launch_bounds__(64) void k_xchg_wait_advance(XchgPeers P, XchgState *st, const int *done) {
+  const int q = threadIdx.x;
+  const int d = done ? *done : 0;
+  const unsigned long long e = st->epoch + 1;
+  const int err = st->err;
+  const unsigned long long seen = q < P.n ? __hip_atomic_load(xchg_flag(P, P.rank, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ~0ull;
+  asm volatile("" ::"v"(d), "v"(err), "v"(seen), "s"(e));
+  if (d) return;                 // (the producing launch took the same early exit: nothing was signalled)
+  if (err || seen < e) xchg_wait(st, P, e);
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  if (threadIdx.x == 0) st->epoch = e;
+}
+
 __global__ void k_xchg_set_abort(XchgState *st, int *flag) { st->abort_done = flag; }
 
 // ------------------------------------------------------------------ host side
@@ -208,7 +204,12 @@ struct PeerComm {
     base[q] = (char *)p;
     ipc_opened.push_back(p);
   }
-  void set_timeout_ms(long long ms) { peers.timeout = ms * 100000ll; }   // 100 MHz ticks
+  XchgPeers *peers_dev = nullptr;    // the same structure in device memory (the folded launches read it through a pointer)
+  void set_timeout_ms(long long ms) { set_timeout_ticks(ms * 100000ll); }   // 100 MHz ticks
+  void set_timeout_ticks(long long ticks) {
+    peers.timeout = ticks;
+    if (peers_dev) memcpy_sync(peers_dev, &peers, sizeof peers, hipMemcpyHostToDevice);
+  }
   void finish() {
     for (int q = 0; q < n; ++q) if (!base[q]) raise(MI_ERR_COMM, "peer exchange: the arena of rank %d was never imported", q);
     peers = XchgPeers{};
@@ -216,6 +217,8 @@ struct PeerComm {
     const char *t = std::getenv("MI355_PEER_TIMEOUT_MS");
     set_timeout_ms(t && *t ? std::atoll(t) : 60000);   // generous: ranks reach their first exchange seconds apart (host-side set-up)
     for (int q = 0; q < n; ++q) peers.arena[q] = base[q];
+    if (!peers_dev) MI_HIP(hipMalloc((void **)&peers_dev, sizeof(XchgPeers)));
+    memcpy_sync(peers_dev, &peers, sizeof peers, hipMemcpyHostToDevice);
     ready = true;
   }
   // Collective and deterministic: every rank calls it in the same order with the same size. Returns the offset.
@@ -259,6 +262,11 @@ struct PeerComm {
     hipLaunchKernelGGL(k_xchg_push, dim3(chunks, n), dim3(1024), 0, s, peers, st, table_off, copy_doubles, src, own_idx, n_own, done);
     MI_HIP(hipGetLastError());
   }
+  void wait_advance(hipStream_t s, const int *done) {
+    if (!ready) raise(MI_ERR_COMM, "peer exchange used before every arena was imported");
+    hipLaunchKernelGGL(k_xchg_wait_advance, dim3(1), dim3(64), 0, s, peers, st, done);
+    MI_HIP(hipGetLastError());
+  }
   // 0, or 1 when a wait has expired since the last call (cleared); synchronises the stream
   std::string err_text;
   int take_error(hipStream_t s) {
@@ -278,6 +286,7 @@ struct PeerComm {
     for (void *p : ipc_opened) (void)hipIpcCloseMemHandle(p);
     if (arena && owns_arena) (void)hipFree(arena);
     if (st) (void)hipFree(st);
+    if (peers_dev) (void)hipFree(peers_dev);
   }
 };
 

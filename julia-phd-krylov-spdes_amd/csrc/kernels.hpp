@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "exchange_dev.hpp"
+
 namespace mi {
 
 constexpr int NT = 256;        // threads per workgroup for all streaming kernels (4 waves)
@@ -1137,6 +1139,15 @@ struct PcgFold {
   // con_in / part_in0 / part_in1 point at copy 0, copy (*in_epoch & 1) is in_stride doubles further
   const unsigned long long *in_epoch;
   long long in_stride;
+  // outputs of a launch that is sharded over ranks and exchanged by peer stores (exchange.hpp): con_out / part_out0 /
+  // part_out1 then point at copy 0 of the table in the OWN arena; every streamed tile stores its results into copy
+  // ((epoch + 1) & 1) of the table in EVERY arena, publishes them and counts itself in; the last of the n_arrive tiles
+  // stores exchange number epoch + 1 into this rank's flag of every arena. The wait (and the advance of `epoch`) is a
+  // one-wave kernel behind the launch — a streaming launch never spins.
+  const XchgPeers *xp;      // device copy (null: outputs stay local)
+  XchgState *xst;
+  long long out_stride;
+  unsigned int n_arrive;
   // deflation (defcg.jl:291-305; nvec == 0: plain pcg). PHASE 1 also leaves per-tile partials of WtA*z; k_defl_mu turns
   // them into mu = WtAW \ (WtA*z) and (W*mu) in local order; PHASE 0 subtracts that from beta*p + z.
   int nvec;
@@ -1181,8 +1192,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   const long long it0 = st->it, it_nxt0 = st->it_nxt, maxit = st->maxit, cap = st->res_cap;
   const double tol = st->tol, rTz0 = st->rTz, old = st->rTz_prev;
   const unsigned long long xe = f.in_epoch ? *f.in_epoch : 0ull;   // (same round trip as the state block)
+  const unsigned long long xo = f.xp ? f.xst->epoch : 0ull;
   asm volatile("" ::"s"(t.mat_off), "s"(t.n), "s"(t.ld), "s"(t.loc_off), "s"(t.row0), "s"(t.active), "s"(t.nrows), "s"(it0),
-               "s"(it_nxt0), "s"(maxit), "s"(cap), "s"(tol), "s"(rTz0), "s"(old), "s"(done0), "s"(xe));
+               "s"(it_nxt0), "s"(maxit), "s"(cap), "s"(tol), "s"(rTz0), "s"(old), "s"(done0), "s"(xe), "s"(xo));
   if (done0) return;
   const long long xoff = (long long)(xe & 1ull) * f.in_stride;
   const double *con_in = f.con_in + xoff, *part_in0 = f.part_in0 + xoff, *part_in1 = PHASE == 0 ? f.part_in1 + xoff : nullptr;
@@ -1267,6 +1279,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     }
   }
 
+  // peer stores of the results: thread i < 4*NR serves slot (i & 3) of row (i >> 2) of this tile, in every arena
+  int x_tgt = -1;
+  if (f.xp && t.active && threadIdx.x < 4 * NR) {
+    const int r = t.row0 + (int)(threadIdx.x >> 2), k = threadIdx.x & 3;
+    if (r < n && k < W) x_tgt = f.tgt[(off + r) * W + k];
+  }
 #if MI355_OPERAND_FIRST
   if (t.active) rows.begin(m, t);  // matrix stream in flight from here on: issued AFTER the prologue's loads (results return in issue order)
 #endif
@@ -1380,19 +1398,29 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
       double y = 0.0;
       if (r < n) {
         y = PHASE == 1 ? sum[k] / e_cnt[k] : sum[k];
+        if (!f.xp) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int tg = e_tgt[k][q];
-          if (tg >= 0) f.con_out[tg] = y;
+          for (int q = 0; q < 4; ++q) {
+            const int tg = e_tgt[k][q];
+            if (tg >= 0) f.con_out[tg] = y;
+          }
         }
       }
       rowc1[ri] = (r < n ? rowv[ri] : 0.0) * y;    // r_g * z-contribution  /  p_g * Ap-contribution
-      if (PHASE == 1) rowy[ri] = y;
+      if (PHASE == 1 || f.xp) rowy[ri] = y;
     }
   }
   if (PHASE == 1 && o_q >= 0 && o_own) f.x[o_g] = o_x + coef * o_a;  // x + alpha*p (cg.jl:97), off the critical path
   __syncthreads();
   MI_FSTAMP(5);   // results scattered
+  const long long xpo = (long long)((xo + 1) & 1ull) * f.out_stride;
+  if (f.xp && x_tgt >= 0) {
+    const XchgPeers &P = *f.xp;
+    const double y = rowy[threadIdx.x >> 2];
+    const char *own = P.arena[P.rank];
+    for (int q = 0; q < P.n; ++q)
+      xchg_store(reinterpret_cast<double *>(reinterpret_cast<char *>(f.con_out) + (P.arena[q] - own)) + xpo + x_tgt, y);
+  }
   if (PHASE == 1 && f.nvec > 0 && (int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + f.nvec) {
     // per-tile partial of WtA*z (defcg.jl:301): sum over this tile's rows of WtA[v, g(row)] * (z-contribution of the row);
     // the second wave does it while the first one reduces the dot products (nvec <= 64)
@@ -1416,8 +1444,34 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     b = wave_sum(b);
     if (threadIdx.x == 0) {
       const int ps = t.active - 1;   // the tile number on one GPU; a tiling-independent slot when the launch is sharded over ranks
-      if (PHASE == 1) { f.part_out1[ps] = a; f.part_out0[ps] = b; }
-      else f.part_out0[ps] = a;
+      if (!f.xp) {
+        if (PHASE == 1) { f.part_out1[ps] = a; f.part_out0[ps] = b; }
+        else f.part_out0[ps] = a;
+      } else {
+        const XchgPeers &P = *f.xp;
+        const char *own = P.arena[P.rank];
+        for (int q = 0; q < P.n; ++q) {
+          const long long d = P.arena[q] - own;
+          xchg_store(reinterpret_cast<double *>(reinterpret_cast<char *>(f.part_out0) + d) + xpo + ps, PHASE == 1 ? b : a);
+          if (PHASE == 1) xchg_store(reinterpret_cast<double *>(reinterpret_cast<char *>(f.part_out1) + d) + xpo + ps, a);
+        }
+      }
+    }
+  }
+  if (f.xp) {
+    // publish. The results went out as system-scope write-through stores (xchg_store): nothing of them stays in an L2, so
+    // no cache write-back is needed — a system-scope fence per tile walks the L2 and cost 8 us per launch with ~290 tiles
+    // (profiles/NOTES.md). Every thread waits for the acknowledgement of its own stores, the barrier collects the
+    // workgroup, and the last tile to count itself in stores the flags: all stores of the launch are complete by then.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int prev = __hip_atomic_fetch_add(&f.xst->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev == f.n_arrive - 1) {
+        __hip_atomic_store(&f.xst->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const XchgPeers &P = *f.xp;
+        for (int q = 0; q < P.n; ++q) __hip_atomic_store(xchg_flag(P, q, P.rank), xo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
   MI_FSTAMP(6);

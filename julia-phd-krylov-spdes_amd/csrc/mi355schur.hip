@@ -376,7 +376,7 @@ int mi_ctx_loopback_init(mi_ctx_t ctx, void *group, int rank) {
     const int bad = ctx->peer->take_error(ctx->stream);
     { std::lock_guard<std::mutex> lk(g->mu); g->selftest_failed += bad; }
     g->barrier();
-    ctx->peer->peers.timeout = keep;
+    ctx->peer->set_timeout_ticks(keep);
     if (g->selftest_failed) {
       ctx->peer_on = false;
       ctx->no_graph = true;

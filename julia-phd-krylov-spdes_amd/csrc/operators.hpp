@@ -347,9 +347,23 @@ struct DenseBlockOp : Operator {
   double *fold_con(bool reduced = false) const { return (reduced ? fold_reduced() : fold_pack.p); }
   double *fold_part0(bool reduced = false) const { return (reduced ? fold_reduced() : fold_pack.p) + fold_con_n; }
   double *fold_part1p(bool reduced = false) const { return fold_p1_off ? (reduced ? fold_reduced() : fold_pack.p) + fold_p1_off : fold_part1.p; }
-  void reduce_fold() {
-    if (xt_on) ctx->peer->push(xt_off, xt_copy, fold_pack.p, own_idx.p, n_own, ctx->stream, nullptr);
+  // peer exchange, default: the folded launch stores its results into every arena itself and signals (kernels.hpp); what
+  // follows the launch is the one-wave wait. MI355_XCHG_PUSH_KERNEL=1: results into the local pack, pushed by k_xchg_push.
+  bool xt_direct = false;
+  int n_active = 0;               // streamed tiles (the ones that count themselves in)
+  void reduce_fold(const int *done) {
+    if (xt_on && xt_direct) ctx->peer->wait_advance(ctx->stream, done);
+    else if (xt_on) ctx->peer->push(xt_off, xt_copy, fold_pack.p, own_idx.p, n_own, ctx->stream, done);
     else ctx->allreduce(fold_pack.p, fold_pack_all.p, fold_pack_n);
+  }
+  void fold_outputs(PcgFold &f) const {   // con_out / part_out0 / part_out1 (+ the peer-store fields) of this operator's launch
+    if (xt_on && xt_direct) {
+      double *t0 = ctx->peer->local(xt_off);
+      f.con_out = t0; f.part_out0 = t0 + fold_con_n; f.part_out1 = fold_p1_off ? t0 + fold_p1_off : nullptr;
+      f.xp = ctx->peer->peers_dev; f.xst = ctx->peer->st; f.out_stride = (long long)xt_copy; f.n_arrive = (unsigned int)n_active;
+    } else {
+      f.con_out = fold_con(); f.part_out0 = fold_part0(); f.part_out1 = scale ? fold_part1p() : nullptr;
+    }
   }
   DevBuf<GemvTile> tiles;
   std::vector<long long> moff_h;  // per local subdomain: element offset of its block in M (row-major, ld_h[dl])
@@ -491,6 +505,8 @@ struct DenseBlockOp : Operator {
         xt_copy = (fold_pack_n + 31) & ~(size_t)31;
         xt_off = c->peer->alloc(2 * xt_copy * sizeof(double));   // (zero since the arena was created: a bump allocator never re-uses)
         xt_on = true;
+        for (const GemvTile &t : tv) n_active += t.active != 0;
+        xt_direct = n_active > 0 && !env_int("MI355_XCHG_PUSH_KERNEL", 0);   // (a rank without a block has nothing to count in: push kernel)
       }
     }
     fold_vec.alloc((size_t)maps.nloc * 4 + 4); fold_vec.zero(c->stream);

@@ -343,14 +343,14 @@ struct Krylov {
     const bool redA = Ad->reduce_over_ranks, redM = Md->reduce_over_ranks;
     f.n_in = phase ? Ad->part_total : Md->part_total;
     if (phase) {  // ΠS launch: reads S contributions + partial p'Ap, writes ΠS contributions + partial r'r, r'z
-      f.con_in = Ad->fold_con(redA); f.con_out = Md->fold_con();
+      f.con_in = Ad->fold_con(redA);
       f.part_in0 = Ad->fold_part0(redA); f.part_in1 = nullptr;
-      f.part_out0 = Md->fold_part0(); f.part_out1 = Md->fold_part1p();
+      Md->fold_outputs(f);
       if (redA && Ad->xt_on) { f.in_epoch = &ctx->peer->st->epoch; f.in_stride = (long long)Ad->xt_copy; }
     } else {      // S launch: reads ΠS contributions + partial r'r, r'z, writes S contributions + partial p'Ap
-      f.con_in = Md->fold_con(redM); f.con_out = Ad->fold_con();
+      f.con_in = Md->fold_con(redM);
       f.part_in0 = Md->fold_part0(redM); f.part_in1 = Md->fold_part1p(redM);
-      f.part_out0 = Ad->fold_part0(); f.part_out1 = nullptr;
+      Ad->fold_outputs(f);
       if (redM && Md->xt_on) { f.in_epoch = &ctx->peer->st->epoch; f.in_stride = (long long)Md->xt_copy; }
     }
     return f;
@@ -406,14 +406,14 @@ struct Krylov {
     if (fold) {
       // 2 launches per iteration: (alpha, x, r, z, r'z, r'r) in the ΠS GEMV; (stop rule, beta, p, Ap, p'Ap) in the S GEMV
       Md->gemv_pcg(1, fold_args(1));
-      if (Md->reduce_over_ranks) Md->reduce_fold();  // ΠS contributions + partial r'r, r'z: union over the ranks
+      if (Md->reduce_over_ranks) Md->reduce_fold(dn);  // ΠS contributions + partial r'r, r'z: union over the ranks
       if (nvec > 0) {  // mu = WtAW \ (WtA * z); W*mu in local order for the S launch (defcg.jl:301-303)
         hipLaunchKernelGGL(k_defl_mu, dim3((Ad->maps.nloc + 1023) / 1024), dim3(1024), 0, s, ws.st, nvec, Md->ntiles, ws.fold_mu.p,
                            ws.LU.p, ws.piv.p, ws.W.p, (long long)n, Ad->maps.nloc, Ad->maps.gidx.p, ws.fold_wm.p, ws.mu.p, ws.fold_wloc.p);
         MI_HIP(hipGetLastError());
       }
       Ad->gemv_pcg(0, fold_args(0));
-      if (Ad->reduce_over_ranks) Ad->reduce_fold();  // S contributions + partial p'Ap: union over the ranks
+      if (Ad->reduce_over_ranks) Ad->reduce_fold(dn);  // S contributions + partial p'Ap: union over the ranks
       return;
     }
     if (fused) {

@@ -93,6 +93,25 @@ def test_config4_full_size_in_process_ranks(pkg, orc, full, world, shard_nn):
     assert n_xchg >= per_it * (res[1] - 1), (n_xchg, res[1])
 
 
+def test_push_kernel_exchange_gives_the_same_bits(pkg, full, monkeypatch):
+    """The exchange has two producers: the folded launches storing into every arena themselves (default), and the local
+    pack pushed by `k_xchg_push` (MI355_XCHG_PUSH_KERNEL=1; also what a rank without a block falls back to). Same tables,
+    same bits."""
+    api, P = pkg.api, full
+    n, b, world = P.sub.n_Γ, P.b_schur, 4
+
+    def rank_main(ctx, r):
+        S, M = sharded_ops(api, ctx, P, r, world, True)
+        ctx.host_barrier.wait(timeout=300)
+        return api.pcg(S, b, np.zeros(n), M)
+
+    direct = run_ranks(api, world, rank_main)
+    monkeypatch.setenv("MI355_XCHG_PUSH_KERNEL", "1")
+    pushed = run_ranks(api, world, rank_main)
+    for r in range(world):
+        assert pushed[r][1] == direct[0][1] and np.array_equal(pushed[r][2], direct[0][2]) and np.array_equal(pushed[r][0], direct[0][0])
+
+
 def test_config4_deflated_and_host_rendezvous(pkg, orc, full):
     """defpcg across 8 in-process ranks at full size (S sharded, NN replicated: the deflated loop all-reduces the slot table
     after every S-apply, also for `WtA = (A W)'`), and the same pcg through the group's host-rendezvous mode (eager

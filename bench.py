@@ -517,8 +517,10 @@ def main():
     ap.add_argument("--kernel-reps", type=int, default=200)
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, RCCL communicator, all-reduces) even with one rank")
-    ap.add_argument("--exchange", choices=["auto", "peer", "rccl"], default="auto",
-                    help="multi-GPU Γ-sum: the one-shot peer exchange when every rank can map its peers' arenas (auto), or RCCL all-reduces")
+    ap.add_argument("--exchange", choices=["auto", "peer", "peer-inlaunch", "rccl"], default="auto",
+                    help="multi-GPU Γ-sum: the one-shot peer exchange when every rank can map its peers' arenas (auto / peer: "
+                         "one-wave wait kernels between the launches; peer-inlaunch: the launches wait for the flags themselves — "
+                         "only when every rank has a GPU of its own; measured equal on one GPU), or RCCL all-reduces")
     ap.add_argument("--shard-precond", action="store_true",
                     help="multi-GPU: shard the Neumann-Neumann blocks like S (two all-reduces per iteration) instead of replicating them")
     ap.add_argument("--workload", choices=["schur", "fullA"], default="schur",
@@ -551,6 +553,7 @@ def main():
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_dist
     peer_on = False
+    peer_inwait = False
     if multi:
         if "RANK" not in os.environ:      # --force-dist from a plain `python bench.py`: a one-rank rendezvous on the loopback
             import socket
@@ -620,7 +623,15 @@ def main():
             peer_on = bool(flag.item())
             if peer_on:
                 ctx.peer_ready()
-            elif args.exchange == "peer":
+                # a launch that waits for its peers' flags keeps its compute units: only when no two ranks share a GPU
+                ident = (os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
+                         os.environ.get("CUDA_VISIBLE_DEVICES"), torch.cuda.current_device())
+                idents = [None] * world
+                dist.all_gather_object(idents, ident)
+                peer_inwait = args.exchange == "peer-inlaunch" and len(set(idents)) == world
+                ctx.set_exchange(2 if peer_inwait else 1)
+                peer_inwait = ctx.query("peer_exchange") == 3          # (needs a fine-grained arena: mode 1 otherwise)
+            elif args.exchange in ("peer", "peer-inlaunch"):
                 raise SystemExit("--exchange peer: the peer exchange could not be set up on every rank")
         if peer_on and (world > 1 or args.force_dist):
             args.shard_precond = True      # both operators sharded: two cheap exchanges per iteration instead of a replicated ΠS stream
@@ -795,12 +806,13 @@ def main():
                        "subdomains_per_gpu": hi - lo,
                        "parallelism": ("single GPU" if not multi else
                                        f"S sharded {hi - lo} subdomain(s)/GPU; NN blocks "
-                                       + ("sharded: folded loop, one peer exchange (xGMI peer stores + flags, csrc/exchange.hpp) behind each of the two launches"
+                                       + ("sharded: folded loop, two peer exchanges per iteration (the launches store into every rank's arena over xGMI and signal; "
+                                          + ("the next launch waits for the flags itself" if peer_inwait else "a one-wave kernel waits for the flags") + ", csrc/exchange.hpp)"
                                           if args.shard_precond and peer_on else
                                           "sharded: 4-launch loop, 2 RCCL all-reduces of the slot tables per iteration" if args.shard_precond
                                           else "replicated: folded loop, 1 exchange of the S launch's contribution table per iteration ("
                                                + ("peer stores" if peer_on else "RCCL all-reduce") + ")")),
-                       "exchange": ("peer" if peer_on else "rccl") if multi else None,
+                       "exchange": (("peer-inlaunch" if peer_inwait else "peer") if peer_on else "rccl") if multi else None,
                        "it": its, "loop_iterations_per_solve": loop_its,
                        "final_relres": relres, "launches_per_iteration": 2 if folded else 4},
             "roofline": roofline,

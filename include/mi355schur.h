@@ -91,7 +91,12 @@ int mi_ctx_comm_destroy(mi_ctx_t ctx);
  * are contexts of the SAME process pass the exporter's `base` instead of a handle); mi_ctx_peer_ready. With RCCL also
  * attached the peer exchange carries the tables of the folded PCG launches and RCCL the generic all-reduces; alone it
  * carries both. mi_ctx_set_exchange(ctx, 0) switches it off again (RCCL for everything), 1 on. Sharded operators must be
- * created in the same order with the same sizes on every rank (their tables sit at equal offsets of every arena). */
+ * created in the same order with the same sizes on every rank (their tables sit at equal offsets of every arena).
+ * Who produces and who waits: the folded PCG launches store their results into every arena themselves (write-through
+ * stores; the last tile of a launch stores the flags) and a one-wave kernel behind the launch waits — mode 1, safe when
+ * several ranks share a GPU (in-process ranks, tests). Mode 2 (mi_ctx_set_exchange(ctx, 2), fine-grained arena only —
+ * otherwise it is mode 1): no kernel in between, the NEXT launch polls the flags with its first matrix loads already in
+ * flight. A waiting launch keeps its compute units, so mode 2 is for one GPU per rank; bench.py selects it then. */
 #define MI_PEER_HANDLE_BYTES 64
 int mi_ctx_peer_init(mi_ctx_t ctx, int rank, int n_ranks, int64_t arena_bytes /* 0: 64 MiB */);
 int mi_ctx_peer_export(mi_ctx_t ctx, void *handle_out /* MI_PEER_HANDLE_BYTES */, void **base_out);
@@ -99,7 +104,7 @@ int mi_ctx_peer_import(mi_ctx_t ctx, int rank, const void *handle, void *same_pr
 int mi_ctx_peer_ready(mi_ctx_t ctx);
 int mi_ctx_set_exchange(mi_ctx_t ctx, int use_peer_exchange);
 /* Introspection for tests and benchmarks: which path ran. NO_GRAPH: 1 when this context launches eagerly (a collective
- * that cannot be captured); PEER_EXCHANGE: 0 off, 1 on, 2 on with a fine-grained arena; GRAPH_REPLAYS: hipGraphLaunch
+ * that cannot be captured); PEER_EXCHANGE: 0 off, 1 on, 2 on with a fine-grained arena, 3 on with in-launch waits; GRAPH_REPLAYS: hipGraphLaunch
  * calls of the solvers so far; EXCHANGES: exchanges this rank has signalled (synchronises the stream). */
 #define MI_QUERY_NO_GRAPH 0
 #define MI_QUERY_PEER_EXCHANGE 1

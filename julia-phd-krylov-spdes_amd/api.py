@@ -177,8 +177,11 @@ class Context:
     def peer_ready(self) -> None:
         check(self._L.mi_ctx_peer_ready(self._h))
 
-    def set_exchange(self, use_peer_exchange: bool) -> None:
-        check(self._L.mi_ctx_set_exchange(self._h, C.c_int(1 if use_peer_exchange else 0)))
+    def set_exchange(self, mode) -> None:
+        """`mi_ctx_set_exchange`: 0 / False — RCCL for everything; 1 / True — peer exchange, one-wave wait kernels between the
+        launches; 2 — peer exchange, the folded launches wait for the flags themselves (only with one GPU per rank: a
+        waiting launch keeps its compute units)."""
+        check(self._L.mi_ctx_set_exchange(self._h, C.c_int(int(mode))))
 
     def query(self, what: str) -> int:
         """`mi_ctx_query`: "no_graph", "peer_exchange", "graph_replays", "exchanges", "spectral_pinv"."""

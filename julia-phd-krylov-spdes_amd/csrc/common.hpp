@@ -281,6 +281,7 @@ struct mi_ctx_s {
   mi::LoopGroup *loop = nullptr;  // in-process test communicator (see LoopGroup); mutually exclusive with comm
   mi::PeerComm *peer = nullptr;   // peer exchange (exchange.hpp): beside RCCL (table exchanges) or alone (also the all-reduce)
   bool peer_on = false;           // every arena imported; mi_ctx_set_exchange can switch it off (RCCL for everything)
+  bool peer_inwait = false;       // mi_ctx_set_exchange(ctx, 2): the folded launches wait for the flags themselves (one GPU per rank)
   int rank = 0, n_ranks = 1;
   bool has_comm() const { return comm != nullptr || loop != nullptr || (peer != nullptr && peer_on); }
   bool use_peer() const { return peer != nullptr && peer_on; }

@@ -28,33 +28,6 @@
 
 namespace mi {
 
-// thread 0 of a workgroup whose stores are all behind a system-scope fence and a barrier: next exchange number to all peers
-__device__ __forceinline__ unsigned long long xchg_signal(XchgState *st, const XchgPeers &P) {
-  const unsigned long long e = st->epoch + 1;
-  st->epoch = e;
-  for (int q = 0; q < P.n; ++q) __hip_atomic_store(xchg_flag(P, q, P.rank), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  return e;
-}
-// lanes 0..n-1 of one wave: until flag q of the own arena has reached e (bounded)
-__device__ __forceinline__ void xchg_wait(XchgState *st, const XchgPeers &P, unsigned long long e) {
-  const int q = threadIdx.x;
-  if (q >= P.n) return;
-  const unsigned long long *f = xchg_flag(P, P.rank, q);
-  const long long t0 = wall_clock64();
-  if (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {   // a wait has expired before: fall through, the solve fails anyway
-    if (st->abort_done) *st->abort_done = 1;
-    return;
-  }
-  while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
-    if (wall_clock64() - t0 > P.timeout) {
-      if (atomicExch(&st->err, 1) == 0) { st->err_rank = q; st->err_epoch = e; st->err_seen = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-      if (st->abort_done) *st->abort_done = 1;
-      return;
-    }
-    __builtin_amdgcn_s_sleep(4);
-  }
-}
-
 // ---- table exchange: this rank's entries of `src` (list own_idx, ascending) into copy (e & 1) of the table in EVERY arena,
 // signal, wait. One launch of (chunks × destinations) workgroups: workgroup (c, q) stores chunk c of the entries into
 // arena q — the stores are 8-byte scatters (slots of 32-byte rows), one workgroup issues about 1.4 of them per ns
@@ -94,7 +67,7 @@ __global__ __launch_bounds__(1024) void k_xchg_push(XchgPeers P, XchgState *st, 
     }
   }
   __syncthreads();
-  if (last_sh && threadIdx.x < 64) xchg_wait(st, P, e_sh);
+  if (last_sh && threadIdx.x < 64) { xchg_wait(st, P, e_sh); __atomic_thread_fence(__ATOMIC_ACQUIRE); }
 }
 
 // ---- generic all-reduce (sum) through per-rank staging slots [2][n_ranks][cap] in every arena: copy, signal + wait, sum
@@ -115,6 +88,7 @@ __global__ __launch_bounds__(64) void k_xchg_signal_wait(XchgPeers P, XchgState 
   if (threadIdx.x == 0) e_sh = xchg_signal(st, P);
   __syncthreads();
   xchg_wait(st, P, e_sh);
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
 __global__ __launch_bounds__(256) void k_xchg_sum(XchgPeers P, const XchgState *st, size_t stage_off, size_t cap,
                                                   double *__restrict__ recv, size_t n, const int *done) {
@@ -150,6 +124,8 @@ __global__ __launch_bounds__(64) void k_xchg_wait_advance(XchgPeers P, XchgState
   if (threadIdx.x == 0) st->epoch = e;
 }
 
+// in-launch waits (PcgFold::x_inwait): the folded loop of a solve starts from the exchange number as it stands now
+__global__ void k_xchg_begin(XchgState *st) { st->xep[0] = st->epoch; st->xep[1] = st->epoch; }
 __global__ void k_xchg_set_abort(XchgState *st, int *flag) { st->abort_done = flag; }
 
 // ------------------------------------------------------------------ host side
@@ -260,6 +236,10 @@ struct PeerComm {
     if (!ready) raise(MI_ERR_COMM, "peer exchange used before every arena was imported");
     const int chunks = std::max(1, (n_own + XCHG_PUSH_CHUNK - 1) / XCHG_PUSH_CHUNK);   // (a rank without entries still signals and waits)
     hipLaunchKernelGGL(k_xchg_push, dim3(chunks, n), dim3(1024), 0, s, peers, st, table_off, copy_doubles, src, own_idx, n_own, done);
+    MI_HIP(hipGetLastError());
+  }
+  void begin_inwait(hipStream_t s) {
+    hipLaunchKernelGGL(k_xchg_begin, dim3(1), dim3(1), 0, s, st);
     MI_HIP(hipGetLastError());
   }
   void wait_advance(hipStream_t s, const int *done) {

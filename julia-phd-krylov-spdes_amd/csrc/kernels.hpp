@@ -1148,6 +1148,12 @@ struct PcgFold {
   XchgState *xst;
   long long out_stride;
   unsigned int n_arrive;
+  // x_inwait (every rank on a GPU of its own — a waiting launch keeps its compute units): no kernel between the launches.
+  // A launch whose inputs come out of an exchange (in_stride != 0) waits for the flags itself, with its first matrix loads
+  // already in flight. The exchange number is then carried like it / it_nxt: a PHASE p launch reads xst->xep[p] and its
+  // lead thread writes xst->xep[1 - p] (the launches alternate), so no workgroup reads a word its own launch writes.
+  const XchgPeers *xpw;     // peers to wait for (device copy)
+  int x_inwait;
   // deflation (defcg.jl:291-305; nvec == 0: plain pcg). PHASE 1 also leaves per-tile partials of WtA*z; k_defl_mu turns
   // them into mu = WtAW \ (WtA*z) and (W*mu) in local order; PHASE 0 subtracts that from beta*p + z.
   int nvec;
@@ -1191,11 +1197,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   const int done0 = st->done;
   const long long it0 = st->it, it_nxt0 = st->it_nxt, maxit = st->maxit, cap = st->res_cap;
   const double tol = st->tol, rTz0 = st->rTz, old = st->rTz_prev;
-  const unsigned long long xe = f.in_epoch ? *f.in_epoch : 0ull;   // (same round trip as the state block)
-  const unsigned long long xo = f.xp ? f.xst->epoch : 0ull;
+  const unsigned long long xo = f.xst ? (f.x_inwait ? f.xst->xep[PHASE] : f.xst->epoch) : 0ull;   // (same round trip as the state block)
+  const unsigned long long xe = f.x_inwait ? xo : (f.in_epoch ? *f.in_epoch : 0ull);
   asm volatile("" ::"s"(t.mat_off), "s"(t.n), "s"(t.ld), "s"(t.loc_off), "s"(t.row0), "s"(t.active), "s"(t.nrows), "s"(it0),
                "s"(it_nxt0), "s"(maxit), "s"(cap), "s"(tol), "s"(rTz0), "s"(old), "s"(done0), "s"(xe), "s"(xo));
   if (done0) return;
+  GemvRows<RPW> rows;
+  if (f.x_inwait && f.in_stride) {
+    // the tables this launch reads are complete when every rank's flag in the own arena has reached the exchange number
+    if (t.active) rows.begin(m, t);      // (the matrix does not depend on them: its first loads travel while the flags are polled)
+    if (threadIdx.x < 64) xchg_wait(f.xst, *f.xpw, xo);
+    __syncthreads();
+    // (the tables sit in fine-grained memory — no level of cache keeps their lines across the peers' stores; the vector
+    // caches were emptied when this launch began and have not seen the tables since)
+    if (__hip_atomic_load(&f.xst->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // expired: the solve fails with MI_ERR_COMM
+  }
+  const bool streaming = f.x_inwait && f.in_stride;
   const long long xoff = (long long)(xe & 1ull) * f.in_stride;
   const double *con_in = f.con_in + xoff, *part_in0 = f.part_in0 + xoff, *part_in1 = PHASE == 0 ? f.part_in1 + xoff : nullptr;
   __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
@@ -1206,9 +1223,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   const int off = t.loc_off, W = f.W, n = t.n;
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
   if (threadIdx.x < NR) { rowc0[threadIdx.x] = 0.0; rowv[threadIdx.x] = 0.0; rowy[threadIdx.x] = 0.0; rowg[threadIdx.x] = 0; }  // visible after the barrier of the sums
-  GemvRows<RPW> rows;
 #if !MI355_OPERAND_FIRST
-  if (t.active) rows.begin(m, t);  // matrix stream in flight from here on
+  if (t.active && !streaming) rows.begin(m, t);  // matrix stream in flight from here on
 #endif
 
   // ---- every load of the prologue is issued before the first barrier (one memory round trip), all contiguous
@@ -1286,7 +1302,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     if (r < n && k < W) x_tgt = f.tgt[(off + r) * W + k];
   }
 #if MI355_OPERAND_FIRST
-  if (t.active) rows.begin(m, t);  // matrix stream in flight from here on: issued AFTER the prologue's loads (results return in issue order)
+  if (t.active && !streaming) rows.begin(m, t);  // matrix stream in flight from here on: issued AFTER the prologue's loads (results return in issue order)
 #endif
   MI_FSTAMP(1);   // all prologue loads and the first matrix group issued
   // ---- scalars
@@ -1300,6 +1316,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
       st->d = d; st->alpha = coef;
       st->rTz_prev = first ? 1.0 : rTz0;
       st->it = it_nxt0;
+      if (f.x_inwait) { f.xst->xep[0] = xo + (f.xp ? 1 : 0); f.xst->epoch = xo; }
     }
   } else {
     const long long it_new = it0 + 1;
@@ -1314,6 +1331,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
       st->it_nxt = it_new;
       if (it_new <= cap) f.res_norm[it_new - 1] = res; else st->overflow = 1;
       if (stop || it_new > cap) st->done = 1;
+      if (f.x_inwait) { f.xst->xep[1] = xo + (f.xp && !(stop || it_new > cap) ? 1 : 0); f.xst->epoch = xo; }
     }
     if (stop || it_new > cap) {        // same decision in every workgroup (it_new > cap: the reference's BoundsError)
       if (f.exit_args && blockIdx.x == 0) {

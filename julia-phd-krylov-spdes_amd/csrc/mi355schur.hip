@@ -430,7 +430,7 @@ int mi_ctx_query(mi_ctx_t ctx, int what, int64_t *out) {
     ctx->use();
     switch (what) {
       case MI_QUERY_NO_GRAPH: *out = ctx->no_graph ? 1 : 0; break;
-      case MI_QUERY_PEER_EXCHANGE: *out = ctx->use_peer() ? (ctx->peer->fine_grained ? 2 : 1) : 0; break;
+      case MI_QUERY_PEER_EXCHANGE: *out = ctx->use_peer() ? (ctx->peer_inwait ? 3 : ctx->peer->fine_grained ? 2 : 1) : 0; break;
       case MI_QUERY_GRAPH_REPLAYS: *out = ctx->n_replays; break;
       case MI_QUERY_SPECTRAL_PINV: *out = spectral_pinv_calls().load(); break;
       case MI_QUERY_EXPERIMENTAL:
@@ -462,6 +462,8 @@ int mi_ctx_set_exchange(mi_ctx_t ctx, int use_peer_exchange) {
     MI_HIP(hipStreamSynchronize(ctx->stream));
     for (auto &kv : ctx->workspaces) kv.second->drop_graphs();
     ctx->peer_on = use_peer_exchange != 0;
+    // (in-launch waits read the tables with no cache maintenance of their own: only with a fine-grained arena)
+    ctx->peer_inwait = use_peer_exchange == 2 && ctx->peer && ctx->peer->fine_grained;
     return MI_OK;
   });
 }

@@ -351,7 +351,8 @@ struct DenseBlockOp : Operator {
   // follows the launch is the one-wave wait. MI355_XCHG_PUSH_KERNEL=1: results into the local pack, pushed by k_xchg_push.
   bool xt_direct = false;
   int n_active = 0;               // streamed tiles (the ones that count themselves in)
-  void reduce_fold(const int *done) {
+  void reduce_fold(const int *done, bool inwait) {
+    if (xt_on && xt_direct && inwait) return;    // the consuming launch waits itself
     if (xt_on && xt_direct) ctx->peer->wait_advance(ctx->stream, done);
     else if (xt_on) ctx->peer->push(xt_off, xt_copy, fold_pack.p, own_idx.p, n_own, ctx->stream, done);
     else ctx->allreduce(fold_pack.p, fold_pack_all.p, fold_pack_n);

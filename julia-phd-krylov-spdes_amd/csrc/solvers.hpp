@@ -327,6 +327,11 @@ struct Krylov {
     return slot->usable ? slot.get() : nullptr;
 #endif
   }
+  // peer exchange with the waits inside the launches: every sharded operator of the loop stores into the arenas itself
+  bool inwait() const {
+    return fold && ctx->peer_inwait && ctx->use_peer() && (Ad->reduce_over_ranks || Md->reduce_over_ranks) &&
+           (!Ad->reduce_over_ranks || (Ad->xt_on && Ad->xt_direct)) && (!Md->reduce_over_ranks || (Md->xt_on && Md->xt_direct));
+  }
   PcgFold fold_args(int phase) const {
     PcgFold f{};
     const size_t nl = (size_t)Ad->maps.nloc;
@@ -353,6 +358,7 @@ struct Krylov {
       Ad->fold_outputs(f);
       if (redM && Md->xt_on) { f.in_epoch = &ctx->peer->st->epoch; f.in_stride = (long long)Md->xt_copy; }
     }
+    if (inwait()) { f.x_inwait = 1; f.xst = ctx->peer->st; f.xpw = ctx->peer->peers_dev; }
     return f;
   }
 
@@ -406,14 +412,14 @@ struct Krylov {
     if (fold) {
       // 2 launches per iteration: (alpha, x, r, z, r'z, r'r) in the ΠS GEMV; (stop rule, beta, p, Ap, p'Ap) in the S GEMV
       Md->gemv_pcg(1, fold_args(1));
-      if (Md->reduce_over_ranks) Md->reduce_fold(dn);  // ΠS contributions + partial r'r, r'z: union over the ranks
+      if (Md->reduce_over_ranks) Md->reduce_fold(dn, inwait());  // ΠS contributions + partial r'r, r'z: union over the ranks
       if (nvec > 0) {  // mu = WtAW \ (WtA * z); W*mu in local order for the S launch (defcg.jl:301-303)
         hipLaunchKernelGGL(k_defl_mu, dim3((Ad->maps.nloc + 1023) / 1024), dim3(1024), 0, s, ws.st, nvec, Md->ntiles, ws.fold_mu.p,
                            ws.LU.p, ws.piv.p, ws.W.p, (long long)n, Ad->maps.nloc, Ad->maps.gidx.p, ws.fold_wm.p, ws.mu.p, ws.fold_wloc.p);
         MI_HIP(hipGetLastError());
       }
       Ad->gemv_pcg(0, fold_args(0));
-      if (Ad->reduce_over_ranks) Ad->reduce_fold(dn);  // S contributions + partial p'Ap: union over the ranks
+      if (Ad->reduce_over_ranks) Ad->reduce_fold(dn, inwait());  // S contributions + partial p'Ap: union over the ranks
       return;
     }
     if (fused) {
@@ -512,6 +518,7 @@ struct Krylov {
       hipLaunchKernelGGL(k_residual, dim3(g), dim3(NT), 0, s, n, ws.b, ws.Ap, ws.r, ws.part_rr, ws.part_bb);
       hipLaunchKernelGGL(k_fold_start, dim3(1), dim3(NT), 0, s, ws.st, ws.part_rr, ws.part_bb, g);
       MI_HIP(hipGetLastError());
+      if (inwait()) ctx->peer->begin_inwait(s);
       return;
     }
     if (fold) {
@@ -521,6 +528,7 @@ struct Krylov {
       MI_EPT_DISPATCH(MI_CALL);
 #undef MI_CALL
       MI_HIP(hipGetLastError());
+      if (inwait()) ctx->peer->begin_inwait(s);
       return;
     }
     if (fused && nvec == 0) {

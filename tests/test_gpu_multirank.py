@@ -112,6 +112,38 @@ def test_push_kernel_exchange_gives_the_same_bits(pkg, full, monkeypatch):
         assert pushed[r][1] == direct[0][1] and np.array_equal(pushed[r][2], direct[0][2]) and np.array_equal(pushed[r][0], direct[0][0])
 
 
+@pytest.mark.parametrize("world,shard_nn", [(2, True), (4, True), (2, False)])
+def test_launches_that_wait_for_their_peers_themselves(pkg, toy, world, shard_nn):
+    """`mi_ctx_set_exchange(ctx, 2)`: no kernel between the folded launches — the consuming launch polls the flags, the
+    exchange number travels like it / it_nxt. Meant for one GPU per rank (a waiting launch keeps its compute units); on one
+    GPU it can only run where the launches of all ranks fit on the chip together: the toy problem (a few dozen small
+    workgroups per rank). Same bits as the wait-kernel mode, and the exchange counter ends where it should."""
+    api, P = pkg.api, toy
+    n, b = P.sub.n_Γ, P.b_schur
+
+    def rank_main(mode):
+        def f(ctx, r):
+            S, M = sharded_ops(api, ctx, P, r, world, shard_nn)
+            ctx.set_exchange(mode)
+            ctx.host_barrier.wait(timeout=300)
+            e0 = ctx.query("exchanges")
+            res = api.pcg(S, b, np.zeros(n), M)
+            e1 = ctx.query("exchanges")
+            res2 = api.pcg(S, b, np.zeros(n), M, maxit=5)          # stopped by maxit: the counter must still be exact
+            y = S * b                                              # a generic all-reduce afterwards uses the same counter
+            return res, res2, y, e1 - e0
+        return f
+
+    kernel_wait = run_ranks(api, world, rank_main(1))
+    in_launch = run_ranks(api, world, rank_main(2))
+    for r in range(world):
+        for k in (0, 1):
+            a, w = in_launch[r][k], kernel_wait[0][k]
+            assert a[1] == w[1] and np.array_equal(a[2], w[2]) and np.array_equal(a[0], w[0])
+        assert np.array_equal(in_launch[r][2], kernel_wait[0][2])
+        assert in_launch[r][3] == kernel_wait[0][3]
+
+
 def test_config4_deflated_and_host_rendezvous(pkg, orc, full):
     """defpcg across 8 in-process ranks at full size (S sharded, NN replicated: the deflated loop all-reduces the slot table
     after every S-apply, also for `WtA = (A W)'`), and the same pcg through the group's host-rendezvous mode (eager

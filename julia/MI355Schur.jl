@@ -31,7 +31,8 @@ import Fem: apply_local_schur, apply_local_schurs, apply_global_schur, apply_neu
 # new names only (none of them is exported by Fem or RecyclingKrylovSolvers)
 export MiContext, MiOperator, MiPrecond,
        LocalSchurs, LocalSchur, MatrixFreeLocalSchurs, GlobalSchur,
-       AssemblyPlan, assemble!, set_values!, SchurSetup, set_blocks!, interior_precond!, interior_iterations
+       AssemblyPlan, assemble!, set_values!, SchurSetup, set_blocks!, interior_precond!, interior_iterations,
+       keep_levels!, interior_solve, use_level_solver!, peer_handle!, peer_connect!, set_exchange!
 
 const lib = get(ENV, "MI355SCHUR_LIB", "libmi355schur")
 const MI_ERR_SINGULAR = Cint(-3)
@@ -304,6 +305,41 @@ end
 """New S_d / ΠS_d on an existing device operator (same maps): Example07's per-realization update without re-creating it."""
 set_blocks!(op::MiOperator, blocks::Vector{Matrix{Float64}}) =
   check(ccall((:mi_dense_set_blocks, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), op.h, reduce(vcat, [vec(B) for B in blocks])))
+
+"""`keep_levels!(plan)`: the next `assemble_local_schurs(plan, …)` keeps the elimination's factors on the device, after which
+`interior_solve(plan, f)` is the exact `A_IIdd \\ f_d` of every subdomain (the reference's Cholesky solve, EPDD.jl:649, as
+level sweeps) and `use_level_solver!(S, plan)` makes a matrix-free operator use it instead of its inner CG."""
+keep_levels!(p::SchurSetup, on::Bool=true) = check(ccall((:mi_schur_setup_keep_levels, lib), Cint, (Ptr{Cvoid}, Cint), p.h, on ? 1 : 0))
+function interior_solve(p::SchurSetup, f::Vector{Float64})
+  u = similar(f)
+  check(ccall((:mi_schur_setup_interior_solve, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), p.h, f, u))
+  u
+end
+use_level_solver!(S::MiOperator, p::SchurSetup) = check(ccall((:mi_schur_matfree_interior_levels, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), S.h, p.h))
+
+# ---------------------------------------------------------------- one Julia worker per GPU
+# The reference's sketch of the distributed apply is `@sync @distributed (+) for idom` (EllipticPdePllDomainDecomposition.jl:
+# 10-14). Here every worker owns a context on its own GPU and a slice of the subdomains (`dom_range` of LocalSchurs /
+# NeumannNeumannSchurPreconditioner); the Γ-sum of every iteration is the library's peer exchange (include/mi355schur.h):
+#   handles = [remotecall_fetch(() -> peer_handle!(ctx, r, np), workers()[r + 1]) for r in 0:np-1]     # 64 bytes each
+#   @everywhere peer_connect!(ctx, myrank, handles)
+# after which `pcg(S, b, x, Πnn)` on every worker runs the sharded loop and returns the same bits everywhere.
+const MI_PEER_HANDLE_BYTES = 64
+function peer_handle!(ctx::MiContext, rank::Integer, n_ranks::Integer)
+  check(ccall((:mi_ctx_peer_init, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Int64), ctx.h, rank, n_ranks, 0))
+  h = Vector{UInt8}(undef, MI_PEER_HANDLE_BYTES); base = Ref{Ptr{Cvoid}}(C_NULL)
+  check(ccall((:mi_ctx_peer_export, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx.h, h, base))
+  h
+end
+function peer_connect!(ctx::MiContext, rank::Integer, handles::Vector{Vector{UInt8}})
+  for q in 0:length(handles)-1
+    q == rank && continue
+    check(ccall((:mi_ctx_peer_import, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}), ctx.h, q, handles[q + 1], C_NULL))
+  end
+  check(ccall((:mi_ctx_peer_ready, lib), Cint, (Ptr{Cvoid},), ctx.h))
+end
+"""0: off; 1: peer exchange with wait kernels between the launches; 2: the launches wait themselves (one GPU per worker)."""
+set_exchange!(ctx::MiContext, mode::Integer) = check(ccall((:mi_ctx_set_exchange, lib), Cint, (Ptr{Cvoid}, Cint), ctx.h, mode))
 
 # ---------------------------------------------------------------- solver drop-ins (whole loop on the GPU)
 # Same positional order, keyword and 3-tuple return as RecyclingKrylovSolvers (cg.jl:14,67; defcg.jl:24,242).

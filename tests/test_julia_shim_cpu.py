@@ -175,5 +175,7 @@ def test_every_ccall_matches_the_c_prototype():
                  "mi_schur_global_device_create", "mi_cg", "mi_pcg", "mi_defcg", "mi_defpcg", "mi_eigcg", "mi_eigpcg",
                  "mi_eigdefcg", "mi_eigdefpcg", "mi_initcg", "mi_initpcg", "mi_assembly_plan_create", "mi_assembly_run",
                  "mi_schur_matfree_set_values", "mi_schur_matfree_rhs", "mi_schur_matfree_interior_solutions",
-                 "mi_schur_setup_create", "mi_schur_setup_run", "mi_nn_pinv", "mi_dense_set_blocks"):
+                 "mi_schur_setup_create", "mi_schur_setup_run", "mi_nn_pinv", "mi_dense_set_blocks",
+                 "mi_schur_setup_keep_levels", "mi_schur_setup_interior_solve", "mi_schur_matfree_interior_levels",
+                 "mi_ctx_peer_init", "mi_ctx_peer_export", "mi_ctx_peer_import", "mi_ctx_peer_ready", "mi_ctx_set_exchange"):
         assert need in seen, f"{need} is not bound by the shim"

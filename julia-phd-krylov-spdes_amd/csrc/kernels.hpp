@@ -1186,10 +1186,12 @@ __device__ __forceinline__ double slot_sum(const double *slots, int g, int W) {
 
 // FOLD_CPT = columns per thread staged in registers: the launch needs max n_Γd <= FOLD_CPT * 256 (<= GEMV_PANEL)
 // FOLD_CPT = columns per thread staged in registers: the launch needs max n_Γd <= FOLD_CPT * 64 * WAVES (<= GEMV_PANEL)
-template <int RPW, int PHASE, int FOLD_CPT, int WAVES>
+// XCHG = false compiles every peer-exchange branch out: the single-GPU launches are the kernel they were before.
+template <int RPW, int PHASE, int FOLD_CPT, int WAVES, bool XCHG>
 __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f) {
   constexpr int NTH = 64 * WAVES, NR = WAVES * RPW;  // threads and rows per workgroup
   SolverState *st = f.st;
+  const bool x_push = XCHG && f.xp != nullptr, x_inwait = XCHG && f.x_inwait != 0;
   // The tile record and the state block are requested together, before the stop flag is looked at (one memory round trip
   // instead of two at the top of every launch; the empty asm takes them all as inputs — without it the compiler sinks
   // every load but `done` below the early exit).
@@ -1197,13 +1199,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
   const int done0 = st->done;
   const long long it0 = st->it, it_nxt0 = st->it_nxt, maxit = st->maxit, cap = st->res_cap;
   const double tol = st->tol, rTz0 = st->rTz, old = st->rTz_prev;
-  const unsigned long long xo = f.xst ? (f.x_inwait ? f.xst->xep[PHASE] : f.xst->epoch) : 0ull;   // (same round trip as the state block)
-  const unsigned long long xe = f.x_inwait ? xo : (f.in_epoch ? *f.in_epoch : 0ull);
+  const unsigned long long xo = XCHG && f.xst ? (x_inwait ? f.xst->xep[PHASE] : f.xst->epoch) : 0ull;   // (same round trip as the state block)
+  const unsigned long long xe = x_inwait ? xo : (f.in_epoch ? *f.in_epoch : 0ull);
   asm volatile("" ::"s"(t.mat_off), "s"(t.n), "s"(t.ld), "s"(t.loc_off), "s"(t.row0), "s"(t.active), "s"(t.nrows), "s"(it0),
                "s"(it_nxt0), "s"(maxit), "s"(cap), "s"(tol), "s"(rTz0), "s"(old), "s"(done0), "s"(xe), "s"(xo));
   if (done0) return;
   GemvRows<RPW> rows;
-  if (f.x_inwait && f.in_stride) {
+  if (x_inwait && f.in_stride) {
     // the tables this launch reads are complete when every rank's flag in the own arena has reached the exchange number
     if (t.active) rows.begin(m, t);      // (the matrix does not depend on them: its first loads travel while the flags are polled)
     if (threadIdx.x < 64) xchg_wait(f.xst, *f.xpw, xo);
@@ -1212,7 +1214,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     // caches were emptied when this launch began and have not seen the tables since)
     if (__hip_atomic_load(&f.xst->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // expired: the solve fails with MI_ERR_COMM
   }
-  const bool streaming = f.x_inwait && f.in_stride;
+  const bool streaming = x_inwait && f.in_stride;
   const long long xoff = (long long)(xe & 1ull) * f.in_stride;
   const double *con_in = f.con_in + xoff, *part_in0 = f.part_in0 + xoff, *part_in1 = PHASE == 0 ? f.part_in1 + xoff : nullptr;
   __shared__ __attribute__((aligned(16))) double xs[GEMV_PANEL];
@@ -1297,7 +1299,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
 
   // peer stores of the results: thread i < 4*NR serves slot (i & 3) of row (i >> 2) of this tile, in every arena
   int x_tgt = -1;
-  if (f.xp && t.active && threadIdx.x < 4 * NR) {
+  if (x_push && t.active && threadIdx.x < 4 * NR) {
     const int r = t.row0 + (int)(threadIdx.x >> 2), k = threadIdx.x & 3;
     if (r < n && k < W) x_tgt = f.tgt[(off + r) * W + k];
   }
@@ -1316,7 +1318,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
       st->d = d; st->alpha = coef;
       st->rTz_prev = first ? 1.0 : rTz0;
       st->it = it_nxt0;
-      if (f.x_inwait) { f.xst->xep[0] = xo + (f.xp ? 1 : 0); f.xst->epoch = xo; }
+      if (x_inwait) { f.xst->xep[0] = xo + (x_push ? 1 : 0); f.xst->epoch = xo; }
     }
   } else {
     const long long it_new = it0 + 1;
@@ -1331,7 +1333,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
       st->it_nxt = it_new;
       if (it_new <= cap) f.res_norm[it_new - 1] = res; else st->overflow = 1;
       if (stop || it_new > cap) st->done = 1;
-      if (f.x_inwait) { f.xst->xep[1] = xo + (f.xp && !(stop || it_new > cap) ? 1 : 0); f.xst->epoch = xo; }
+      if (x_inwait) { f.xst->xep[1] = xo + (x_push && !(stop || it_new > cap) ? 1 : 0); f.xst->epoch = xo; }
     }
     if (stop || it_new > cap) {        // same decision in every workgroup (it_new > cap: the reference's BoundsError)
       if (f.exit_args && blockIdx.x == 0) {
@@ -1416,7 +1418,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
       double y = 0.0;
       if (r < n) {
         y = PHASE == 1 ? sum[k] / e_cnt[k] : sum[k];
-        if (!f.xp) {
+        if (!x_push) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int tg = e_tgt[k][q];
@@ -1425,14 +1427,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
         }
       }
       rowc1[ri] = (r < n ? rowv[ri] : 0.0) * y;    // r_g * z-contribution  /  p_g * Ap-contribution
-      if (PHASE == 1 || f.xp) rowy[ri] = y;
+      if (PHASE == 1 || x_push) rowy[ri] = y;
     }
   }
   if (PHASE == 1 && o_q >= 0 && o_own) f.x[o_g] = o_x + coef * o_a;  // x + alpha*p (cg.jl:97), off the critical path
   __syncthreads();
   MI_FSTAMP(5);   // results scattered
   const long long xpo = (long long)((xo + 1) & 1ull) * f.out_stride;
-  if (f.xp && x_tgt >= 0) {
+  if (x_push && x_tgt >= 0) {
     const XchgPeers &P = *f.xp;
     const double y = rowy[threadIdx.x >> 2];
     const char *own = P.arena[P.rank];
@@ -1462,7 +1464,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
     b = wave_sum(b);
     if (threadIdx.x == 0) {
       const int ps = t.active - 1;   // the tile number on one GPU; a tiling-independent slot when the launch is sharded over ranks
-      if (!f.xp) {
+      if (!x_push) {
         if (PHASE == 1) { f.part_out1[ps] = a; f.part_out0[ps] = b; }
         else f.part_out0[ps] = a;
       } else {
@@ -1476,7 +1478,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemv_pcg(DenseMeta m, PcgFold f)
       }
     }
   }
-  if (f.xp) {
+  if (x_push) {
     // publish. The results went out as system-scope write-through stores (xchg_store): nothing of them stays in an L2, so
     // no cache write-back is needed — a system-scope fence per tile walks the L2 and cost 8 us per launch with ~290 tiles
     // (profiles/NOTES.md). Every thread waits for the acknowledgement of its own stores, the barrier collects the

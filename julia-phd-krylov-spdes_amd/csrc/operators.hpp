@@ -558,8 +558,10 @@ struct DenseBlockOp : Operator {
   // One launch of the folded PCG pair (kernels.hpp k_gemv_pcg); PHASE 1 on the ΠS operator, 0 on S.
   void gemv_pcg(int phase, const PcgFold &f) {
     if (!ntiles) return;
-#define MI_PCG3(R, C, V) do { if (phase) hipLaunchKernelGGL((k_gemv_pcg<R, 1, C, V>), dim3(ntiles), dim3(64 * V), 0, ctx->stream, meta, f); \
-                              else hipLaunchKernelGGL((k_gemv_pcg<R, 0, C, V>), dim3(ntiles), dim3(64 * V), 0, ctx->stream, meta, f); } while (0)
+    const bool xchg = f.xp != nullptr || f.x_inwait != 0;   // this launch stores into the peers' arenas and / or waits for them
+#define MI_PCG4(R, P, C, V) do { if (xchg) hipLaunchKernelGGL((k_gemv_pcg<R, P, C, V, true>), dim3(ntiles), dim3(64 * V), 0, ctx->stream, meta, f); \
+                                 else hipLaunchKernelGGL((k_gemv_pcg<R, P, C, V, false>), dim3(ntiles), dim3(64 * V), 0, ctx->stream, meta, f); } while (0)
+#define MI_PCG3(R, C, V) do { if (phase) MI_PCG4(R, 1, C, V); else MI_PCG4(R, 0, C, V); } while (0)
 #define MI_PCG2(R, V) do { const int c = (max_ld + 64 * V - 1) / (64 * V); \
                            if (c <= 2) MI_PCG3(R, 2, V); else if (c == 3) MI_PCG3(R, 3, V); else if (c == 4) MI_PCG3(R, 4, V); \
                            else if (c == 5) MI_PCG3(R, 5, V); else if (c == 6) MI_PCG3(R, 6, V); else MI_PCG3(R, 8, V); } while (0)
@@ -568,6 +570,7 @@ struct DenseBlockOp : Operator {
 #undef MI_PCG
 #undef MI_PCG2
 #undef MI_PCG3
+#undef MI_PCG4
     MI_HIP(hipGetLastError());
   }
   bool same_maps(const DenseBlockOp &o) const {

@@ -224,50 +224,148 @@ typedef double gj_d4 __attribute__((ext_vector_type(4)));
 // doubles of LDS (`scr`; broadcast reads, no v_readlane chain, no second wave): ~70 instructions per step instead of
 // ~200 with whole rows per lane and 64 v_readlanes — the 32-step chain is the critical path of the whole level elimination
 // (every block step waits for it), so this is the kernel that sets the set-up's time.
+// In-place Gauss-Jordan inverse of the 32 x 32 block at (o, o) of an LDS matrix, by 32 lanes of wave 0: lane r keeps row r
+// in registers (32 doubles); a step broadcasts the pivot row with v_readlane (uniform values, straight into the FMAs'
+// scalar operand) — no LDS round trip and no barrier inside the 32-step chain, which is the serial part of every block
+// step of the elimination (the LDS version with half rows per lane took 0.4 us per step, this one 0.1).
+__device__ __forceinline__ double gj_readlane(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void gj_inv32(double *M, int LD, int o, double *scr) {
+  (void)scr;
   if (threadIdx.x < 64) {
-    const int r = threadIdx.x & 31, h = threadIdx.x >> 5;
-    double a[16];
+    const int r = threadIdx.x & 31;          // (lanes 32..63 mirror lanes 0..31: the wave stays convergent, only the lower half stores)
+    double a[32];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = M[(o + r) * LD + o + 16 * h + c];
-    double *prow = scr, *fcol = scr + 32;
+    for (int c = 0; c < 32; ++c) a[c] = M[(o + r) * LD + o + c];
 #pragma unroll
     for (int p = 0; p < 32; ++p) {
-      constexpr int dummy = 0; (void)dummy;
-      const int ph = p >> 4, pc = p & 15;
-      if (h == ph) fcol[r] = a[pc];
-      if (r == p) {
+      const double piv = 1.0 / gj_readlane(a[p], p);
+      const double f = a[p];
+      const double fp = f * piv;
+      const bool me = r == p;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) prow[16 * h + c] = a[c];
+      for (int c = 0; c < 32; ++c) {
+        const double pr = gj_readlane(a[c], p);        // row p before this step
+        if (c == p) a[c] = me ? piv : -fp;
+        else a[c] = me ? pr * piv : a[c] - fp * pr;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const double piv = 1.0 / prow[p];
-      const double f = fcol[r];
-      double pr[16];
+    }
+    if (threadIdx.x < 32) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) pr[c] = prow[16 * h + c] * piv;      // the scaled pivot row (this lane's half)
-      if (r == p) {
+      for (int c = 0; c < 32; ++c) M[(o + r) * LD + o + c] = a[c];
+    }
+  }
+}
+#ifndef MI355_GJ_BULK_DELAY
+#define MI355_GJ_BULK_DELAY 0      // x 8128 cycles of head start for the look-ahead tile: measured +3 us per launch per unit (the other tiles have no slack: the launch is bandwidth-bound while they load)
+#endif
+#ifndef MI355_GJ_INV_RECURSIVE
+#define MI355_GJ_INV_RECURSIVE 0   // 1: the 2 x 2 block recursion over two 32-step register inversions (25 us per pivot block)
+#endif
+// inverse of a 4 x 4 matrix (row-major m) whose leading 2 x 2 block and its Schur complement are non-singular (pivot blocks of
+// an SPD matrix are): [A B; C D]^{-1} = [Ai + X Si V, -X Si; -Si V, Si],  Ai = A^{-1}, X = Ai B, V = C Ai, S = D - C X, Si = S^{-1}
+__device__ __forceinline__ void gj_inv4(const double (&m)[16], double (&p)[16]) {
+  const double da = 1.0 / (m[0] * m[5] - m[1] * m[4]);
+  const double a00 = m[5] * da, a01 = -m[1] * da, a10 = -m[4] * da, a11 = m[0] * da;
+  const double x00 = a00 * m[2] + a01 * m[6], x01 = a00 * m[3] + a01 * m[7], x10 = a10 * m[2] + a11 * m[6], x11 = a10 * m[3] + a11 * m[7];
+  const double v00 = m[8] * a00 + m[9] * a10, v01 = m[8] * a01 + m[9] * a11, v10 = m[12] * a00 + m[13] * a10, v11 = m[12] * a01 + m[13] * a11;
+  const double s00 = m[10] - (m[8] * x00 + m[9] * x10), s01 = m[11] - (m[8] * x01 + m[9] * x11);
+  const double s10 = m[14] - (m[12] * x00 + m[13] * x10), s11 = m[15] - (m[12] * x01 + m[13] * x11);
+  const double ds = 1.0 / (s00 * s11 - s01 * s10);
+  const double i00 = s11 * ds, i01 = -s01 * ds, i10 = -s10 * ds, i11 = s00 * ds;
+  const double y00 = x00 * i00 + x01 * i10, y01 = x00 * i01 + x01 * i11, y10 = x10 * i00 + x11 * i10, y11 = x10 * i01 + x11 * i11;   // X Si
+  const double z00 = i00 * v00 + i01 * v10, z01 = i00 * v01 + i01 * v11, z10 = i10 * v00 + i11 * v10, z11 = i10 * v01 + i11 * v11;   // Si V
+  p[0] = a00 + (x00 * z00 + x01 * z10); p[1] = a01 + (x00 * z01 + x01 * z11); p[2] = -y00; p[3] = -y01;
+  p[4] = a10 + (x10 * z00 + x11 * z10); p[5] = a11 + (x10 * z01 + x11 * z11); p[6] = -y10; p[7] = -y11;
+  p[8] = -z00; p[9] = -z01; p[10] = i00; p[11] = i01;
+  p[12] = -z10; p[13] = -z11; p[14] = i10; p[15] = i11;
+}
+// In-place inverse of a 64 x 64 SPD block in LDS (row stride LD) by 256 threads: block Gauss-Jordan with 4 x 4 pivots —
+// 16 block steps instead of 64 scalar ones. A step: every thread inverts the pivot block M[K, K] in registers (redundantly:
+// no broadcast of the result needed); thread (k, j) forms one entry of the row panel R = P M[K, :] (columns K: P itself);
+// then D = C - M[:, K] R is ONE 16 x 16 x 4 matrix-core op per 16 x 16 block (C = M, zero in columns K, so those become the
+// column panel -M[:, K] P); rows K take R. Two barriers per step. `Rb`: 4 x 68 doubles of scratch.
+// (The scalar chain this replaces — two 32-step register inversions — took 24 of the 25 us of a pivot-block inversion,
+// tools/probes/inv_probe.hip.)
+#ifndef GJ_STAMP
+#define GJ_STAMP(i)
+#endif
+__device__ __forceinline__ void gj_invert_block64(double *M, int LD, double *Rb) {
+  constexpr int RL = 68;
+  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = l & 15, lk = l >> 4;
+#pragma unroll 1
+  for (int s = 0; s < 16; ++s) {
+    const int k0 = 4 * s;
+    double m[16], p[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) a[c] = pr[c];
-        if (h == ph) a[pc] = piv;
-      } else {
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) a[c] -= f * pr[c];
-        if (h == ph) a[pc] = -f * piv;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();                                  // the next step overwrites prow / fcol
+      for (int b = 0; b < 4; ++b) m[4 * a + b] = M[(k0 + a) * LD + k0 + b];
+    GJ_STAMP(0);
+    gj_inv4(m, p);
+    GJ_STAMP(1);
+    {
+      double q0, q1, q2, q3;                       // row wv of P (wave-uniform choice)
+      if (wv == 0) { q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; }
+      else if (wv == 1) { q0 = p[4]; q1 = p[5]; q2 = p[6]; q3 = p[7]; }
+      else if (wv == 2) { q0 = p[8]; q1 = p[9]; q2 = p[10]; q3 = p[11]; }
+      else { q0 = p[12]; q1 = p[13]; q2 = p[14]; q3 = p[15]; }
+      const int j = l, jj = j & 3;
+      const bool inK = (j >> 2) == s;
+      // (unconditional loads, then the choice: a load under `?:` becomes a branch with its own wait — four serial LDS round trips)
+      const double w0 = M[(k0 + 0) * LD + j], w1 = M[(k0 + 1) * LD + j], w2 = M[(k0 + 2) * LD + j], w3 = M[(k0 + 3) * LD + j];
+      const double v0 = inK ? (jj == 0 ? 1.0 : 0.0) : w0, v1 = inK ? (jj == 1 ? 1.0 : 0.0) : w1;
+      const double v2 = inK ? (jj == 2 ? 1.0 : 0.0) : w2, v3 = inK ? (jj == 3 ? 1.0 : 0.0) : w3;
+      Rb[wv * RL + j] = ((q0 * v0 + q1 * v1) + q2 * v2) + q3 * v3;
+    }
+    GJ_STAMP(2);
+    __syncthreads();
+    GJ_STAMP(3);
+    const double aop = M[(16 * wv + lc) * LD + k0 + lk];        // M[row block wv][K]: A[row = lc][k = lk]
+    const bool krows = wv == (s >> 2);
+    const int vk = s & 3;
+    double rb[4];
+    gj_d4 d[4];
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj) {                            // every operand first (one LDS round trip), then the matrix cores, then the stores
+      const int col = 16 * bj + lc;
+      rb[bj] = Rb[lk * RL + col];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) d[bj][v] = M[(16 * wv + lk + 4 * v) * LD + col];
     }
 #pragma unroll
-    for (int c = 0; c < 16; ++c) M[(o + r) * LD + o + 16 * h + c] = a[c];
+    for (int bj = 0; bj < 4; ++bj) {
+      const bool cK = ((16 * bj + lc) >> 2) == s;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) d[bj][v] = cK ? 0.0 : d[bj][v];
+      d[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, -rb[bj], d[bj], 0, 0, 0);
+    }
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj) {
+      const int col = 16 * bj + lc;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) M[(16 * wv + lk + 4 * v) * LD + col] = (krows && v == vk) ? rb[bj] : d[bj][v];   // row 16 wv + lk + 4 v is pivot row k0 + lk exactly then
+    }
+    GJ_STAMP(4);
+    __syncthreads();
+    GJ_STAMP(5);
   }
+  // symmetric to the last bit (the update kernels read P as symmetric): mirror the upper triangle
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    if (j > i) M[j * LD + i] = M[i * LD + j];
+  }
+  __syncthreads();
 }
 // in-place inverse of the SPD GJ_B x GJ_B block in LDS (row stride LD; identity beyond the matrix' end), 256 threads. GJ_B = 64:
 //   [A B; B' D]^{-1} = [P + Y X', -Y; -Y', S^{-1}],  P = A^{-1},  X = P B,  S = D - B' X,  Y = X S^{-1}
 // two 32-step register inversions (the serial part) and five 32 x 32 x 32 products; `W` = 32 x LD doubles of scratch, `scr` = 64 more.
 __device__ __forceinline__ void gj_invert_block(double *M, int LD, double *W, double *scr) {
+  if (GJ_B == 64 && !MI355_GJ_INV_RECURSIVE) { gj_invert_block64(M, LD, W); return; }
   if (GJ_B == 32) {
     gj_inv32(M, LD, 0, scr);
     __syncthreads();
@@ -382,11 +480,31 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   // LDS so that both stores are 128-byte segments). Storage stays full: the pick kernels and the next step's panel loads
   // read any entry.
   if (bx > by) return;
+#if defined(MI355_GJ_DIAG) && MI355_GJ_DIAG == 2
+  if (!special) return;   // timing experiment: only the chain (look-ahead tile + inversion) runs
+#endif
   const int i0 = bx * GJ_T, j0 = by * GJ_T;
+#ifdef MI355_GJ_STAMPS
+  const bool dbg = step == 120 && kb == 2 && threadIdx.x == 0 && (special || ((bx * 7 + by * 3 + dz) % 29) == 0);
+  long long ts[6] = {0, 0, 0, 0, 0, 0};
+  if (dbg) ts[0] = wall_clock64();
+#define GJ_KSTAMP(i) do { if (dbg) ts[i] = wall_clock64(); } while (0)
+#else
+#define GJ_KSTAMP(i)
+#endif
+#if MI355_GJ_BULK_DELAY > 0
+  // experiment: the other tiles let the look-ahead tile's loads go first (off: it made every launch longer)
+  if (ahead && !special) for (int q = 0; q < MI355_GJ_BULK_DELAY; ++q) __builtin_amdgcn_s_sleep(127);
+#endif
   // LDS: A[K, J] / R (GJ_B x 65) and A[I, K] (64 x (GJ_B + 1)): 33.4 KB with a 32-wide pivot block (three workgroups per CU),
   // 66.6 KB with a 64-wide one (two). The pivot inverse P is NOT staged: every lane keeps the GJ_B / 4 entries it feeds to
   // the matrix cores in registers (one request per entry, served by L2: every tile reads the same 32 KB).
-  constexpr int LDS_R = GJ_B * (GJ_T + 1), LDS_CC = GJ_T * (GJ_B + 1);
+  // With a pivot block as wide as a tile A[I, K] is not staged either: every lane holds the 16 entries of its row that it
+  // feeds to the matrix cores (CC_REGS). The second buffer is then only the scratch of the look-ahead inversion: 50 KB per
+  // workgroup, THREE workgroups per CU — the 530-620 tiles of a config-3 launch are resident at once instead of running
+  // a second round for the last few (measured: the tile loop alone 44 -> see profiles/NOTES.md).
+  constexpr bool CC_REGS = GJ_B == GJ_T;
+  constexpr int LDS_R = GJ_B * (GJ_T + 1), LDS_CC = CC_REGS ? GJ_H * (GJ_T + 1) + 64 : GJ_T * (GJ_B + 1);
   static_assert(LDS_R + LDS_CC >= GJ_T * (GJ_T + 1), "the mirror image of a tile is staged in the R and Cc buffers");
   __shared__ double lds[LDS_R + LDS_CC];
   double (&R)[GJ_B][GJ_T + 1] = *reinterpret_cast<double (*)[GJ_B][GJ_T + 1]>(lds);           // A[K, J] first, then R = P * A[K, J], then (look-ahead tile) the next pivot block
@@ -405,8 +523,15 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
     const int t = e % GJ_B, c = e / GJ_B;        // A[k0 + t, j0 + c]: consecutive threads walk down a column
     Ak[t][c] = (t < bs && j0 + c < n) ? A[(k0 + t) + (size_t)(j0 + c) * n] : 0.0;
   }
-  for (int t = wv; t < GJ_B; t += 4)             // A[i0 + l, k0 + t]
-    Cc[l][t] = (t < bs && i0 + l < n) ? A[(i0 + l) + (size_t)(k0 + t) * n] : 0.0;
+  double cb[GJ_B / 4];                           // CC_REGS: A[i0 + 16 wv + lc, k0 + 4 q + lk]
+  if (CC_REGS) {
+    const int ir = i0 + 16 * wv + lc;
+#pragma unroll
+    for (int q = 0; q < GJ_B / 4; ++q) cb[q] = (4 * q + lk < bs && ir < n) ? A[ir + (size_t)(k0 + 4 * q + lk) * n] : 0.0;
+  } else {
+    for (int t = wv; t < GJ_B; t += 4)           // A[i0 + l, k0 + t]
+      Cc[l][t] = (t < bs && i0 + l < n) ? A[(i0 + l) + (size_t)(k0 + t) * n] : 0.0;
+  }
   // the old entries this lane will update (D layout of the transposed product): i = i0 + 16 wv + lc, j = j0 + 16 jt + lk + 4 v
   const int i = i0 + 16 * wv + lc;
   gj_d4 acc[4];
@@ -422,6 +547,7 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   // (D[j][i] = Σ_u P[u][j] (-A[i][k0 + u])); the diagonal tile (kb, kb) becomes P itself.
   const bool kcol = GJ_B == GJ_T && by == kb;
   __syncthreads();
+  GJ_KSTAMP(1);   // operands loaded
   if (!kcol) {
     gj_d4 d[NQ];
 #pragma unroll
@@ -449,7 +575,7 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   // acc[jt] (rows j, cols i) -= R[K, J_jt]' * Cc[I, K]'  ==  (A_ij - A_iK (P A_Kj))'
 #pragma unroll
   for (int kk = 0; kk < GJ_B; kk += 4) {
-    const double bneg = -Cc[16 * wv + lc][kk + lk];
+    const double bneg = CC_REGS ? -cb[kk / 4] : -Cc[16 * wv + lc][kk + lk];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(R[kk + lk][16 * jt + lc], bneg, acc[jt], 0, 0, 0);
   }
@@ -465,7 +591,7 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
       double val = acc[jt][v];                                                 // A_ij - A_iK (P A_Kj);  block column K: -(A_iK P)[i, j - k0]
       if (ik && jk) val = Pcur[(i - k0) + (size_t)(j - k0) * GJ_B];
       else if (ik) val = R[i - k0][jl];                                        // (P A_Kj)[i - k0, j]
-      else if (jk && !kcol) {                                                  // -(A_iK P)[i, j - k0]   (32-wide pivot block inside a 64-wide tile)
+      else if (!CC_REGS && jk && !kcol) {                                      // -(A_iK P)[i, j - k0]   (32-wide pivot block inside a 64-wide tile)
         double s2 = 0.0;
         for (int u = 0; u < GJ_B; ++u) s2 += Cc[16 * wv + lc][u] * Pcur[u + (size_t)(j - k0) * GJ_B];
         val = -s2;
@@ -473,6 +599,10 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
       O[i + (size_t)j * n] = val;
       acc[jt][v] = val;
     }
+  GJ_KSTAMP(2);   // tile updated and stored
+#ifdef MI355_GJ_STAMPS
+  if (dbg && !special) printf("tile %2d %2d dom %d: start %lld loaded +%lld updated +%lld\n", bx, by, dz, ts[0], ts[1] - ts[0], ts[2] - ts[0]);
+#endif
   if (bx != by) {                                // the mirror image: M[j,i] = σ'(i) σ'(j) M[i,j], σ' = -1 below k1 (swept after this step)
     __syncthreads();                             // R, Cc are read for the last time above
     double *T = lds;                             // [GJ_T][GJ_T + 1]
@@ -496,6 +626,9 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
     return;
   }
   if (!special) return;
+#if defined(MI355_GJ_DIAG) && MI355_GJ_DIAG == 1
+  return;      // timing experiment: no look-ahead inversion (results are wrong)
+#endif
   // Look-ahead: this diagonal tile holds the next pivot block (rows / columns k1 .. k1 + bs1 of the updated matrix); its inverse
   // goes to the other half of P. R becomes the landing zone (row stride GJ_T + 1), Cc the scratch of the block inversion.
   __syncthreads();
@@ -510,9 +643,13 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
     }
   __syncthreads();
   static_assert(LDS_CC >= GJ_H * (GJ_T + 1) + 64 || GJ_B == 32, "scratch of the block inversion lives in the Cc buffer");
-  gj_invert_block(&R[0][0], GJ_T + 1, &Cc[0][0], &Cc[0][0] + (GJ_B == 32 ? 0 : GJ_H * (GJ_T + 1)));
+  gj_invert_block(&R[0][0], GJ_T + 1, lds + LDS_R, lds + LDS_R + (GJ_B == 32 ? 0 : GJ_H * (GJ_T + 1)));
+  GJ_KSTAMP(3);   // pivot block inverted
   double *Pn = dm.P + ((kb + 1) & 1) * (GJ_B * GJ_B);
   for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) Pn[e] = R[e % GJ_B][e / GJ_B];
+#ifdef MI355_GJ_STAMPS
+  if (dbg) printf("LOOK-AHEAD tile %2d %2d dom %d: start %lld loaded +%lld updated +%lld inverted +%lld (n = %d)\n", bx, by, dz, ts[0], ts[1] - ts[0], ts[2] - ts[0], ts[3] - ts[0], n);
+#endif
 }
 // ---- the end of a subdomain's chain: S (upper triangle mirrored) = A_ΓΓ - B' Z_0 B; w = B' (Z_0 g_0)
 __global__ __launch_bounds__(256) void k_gj_final_pick(int ndom, const GjDom *__restrict__ doms, const int *__restrict__ c_ptr,

@@ -264,7 +264,7 @@ __device__ __forceinline__ void gj_inv32(double *M, int LD, int o, double *scr) 
 #define MI355_GJ_BULK_DELAY 0      // x 8128 cycles of head start for the look-ahead tile: measured +3 us per launch per unit (the other tiles have no slack: the launch is bandwidth-bound while they load)
 #endif
 #ifndef MI355_GJ_INV_RECURSIVE
-#define MI355_GJ_INV_RECURSIVE 0   // 1: the 2 x 2 block recursion over two 32-step register inversions (25 us per pivot block)
+#define MI355_GJ_INV_RECURSIVE 0   // 1: the 2 x 2 block recursion over two 32-step register inversions (25 us per pivot block instead of 21)
 #endif
 // inverse of a 4 x 4 matrix (row-major m) whose leading 2 x 2 block and its Schur complement are non-singular (pivot blocks of
 // an SPD matrix are): [A B; C D]^{-1} = [Ai + X Si V, -X Si; -Si V, Si],  Ai = A^{-1}, X = Ai B, V = C Ai, S = D - C X, Si = S^{-1}
@@ -289,8 +289,10 @@ __device__ __forceinline__ void gj_inv4(const double (&m)[16], double (&p)[16]) 
 // no broadcast of the result needed); thread (k, j) forms one entry of the row panel R = P M[K, :] (columns K: P itself);
 // then D = C - M[:, K] R is ONE 16 x 16 x 4 matrix-core op per 16 x 16 block (C = M, zero in columns K, so those become the
 // column panel -M[:, K] P); rows K take R. Two barriers per step. `Rb`: 4 x 68 doubles of scratch.
-// (The scalar chain this replaces — two 32-step register inversions — took 24 of the 25 us of a pivot-block inversion,
-// tools/probes/inv_probe.hip.)
+// (The scalar chain this replaces — two 32-step register inversions — took 24 of the 25 us of a pivot-block inversion; this
+// one takes 21, 1.3 us per block step of which 0.7-0.9 are the four matrix-core ops with their operand moves. A variant that
+// keeps the matrix in registers and moves only the pivot rows / columns through LDS measured the same 21 us: the tiles'
+// LDS traffic is not what a step waits for. tools/probes/inv_probe.hip.)
 #ifndef GJ_STAMP
 #define GJ_STAMP(i)
 #endif

@@ -260,8 +260,9 @@ __device__ __forceinline__ void gj_inv32(double *M, int LD, int o, double *scr) 
     }
   }
 }
-#ifndef MI355_GJ_BULK_DELAY
-#define MI355_GJ_BULK_DELAY 0      // x 8128 cycles of head start for the look-ahead tile: measured +3 us per launch per unit (the other tiles have no slack: the launch is bandwidth-bound while they load)
+#ifndef MI355_GJ_HEAD
+#define MI355_GJ_HEAD 0            // 0 (default): look-ahead — the tile holding the NEXT pivot block inverts it at the END of the launch (161.5 ms per
+                                   // config-3 realization); 1: the pivot block of a step is inverted at the HEAD of its own launch (167.3 ms)
 #endif
 #ifndef MI355_GJ_INV_RECURSIVE
 #define MI355_GJ_INV_RECURSIVE 0   // 1: the 2 x 2 block recursion over two 32-step register inversions (25 us per pivot block instead of 21)
@@ -454,12 +455,31 @@ __global__ __launch_bounds__(256) void k_gj_pivot(int step, int kb, int ndom, co
 // the trailing update computed TRANSPOSED — the instruction's row index runs over the tile's columns j, its column index
 // over the tile's rows i — so that a lane's four results sit in 16-lane groups of consecutive i: loads and stores of the
 // column-major matrix are 128-byte segments. Wave v owns rows 16 v .. 16 v + 15 of the tile.
-__global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, const GjStep *__restrict__ steps,
-                                                   const GjDom *__restrict__ doms) {
-  const int dz = blockIdx.z;   // (the subdomain as the FASTEST grid dimension, so that every look-ahead tile is dispatched in the first round, was measured: 55.8 us per launch against 51.7 — neighbouring workgroups then work on different matrices)
+__device__ __forceinline__ unsigned *gj_ready_flag(const GjDom &dm) { return reinterpret_cast<unsigned *>(dm.P + 2 * GJ_B * GJ_B); }
+__global__ void k_gj_reset(int ndom, const GjDom *__restrict__ doms) {
+  if ((int)threadIdx.x < ndom) *gj_ready_flag(doms[threadIdx.x]) = 0u;
+}
+__global__ __launch_bounds__(256, 3) void k_gj_update(int step, int kb, int ndom, const GjStep *__restrict__ steps,
+                                                   const GjDom *__restrict__ doms, unsigned seq, int tiles_x) {
+  // HEAD (MI355_GJ_HEAD=1, measured and not the default): the pivot block of THIS step is inverted at the head of the launch
+  // by its own workgroup while every other tile loads its operands (the bandwidth-bound 7-10 us of a launch); the others
+  // then wait for a per-subdomain flag and fetch P; no separate first-pivot launch per level. Small levels gain (37 us per
+  // launch against ~45), the large ones lose more: their waiting tiles keep compute units that the look-ahead form uses.
+  constexpr bool HEAD = MI355_GJ_HEAD && GJ_B == GJ_T;
+  // HEAD: a 1-D grid whose FIRST ndom workgroups are the pivot tiles of the subdomains — dispatched before any tile that
+  // will wait for them, whatever the number of resident workgroups (with the pivot tile merely first in its subdomain's
+  // slab, slabs beyond the resident set started their inversion only when earlier slabs had finished: 128 us launches).
+  // `tiles_x` = tiles per row of the (square) tile grid.
+  int dz, gbx, gby;
+  if (HEAD) {
+    const int b = blockIdx.x;
+    if (b < ndom) { dz = b; gbx = gby = kb; }
+    else { const int t = b - ndom; gbx = t % tiles_x; gby = (t / tiles_x) % tiles_x; dz = t / (tiles_x * tiles_x); }
+  } else { dz = blockIdx.z; gbx = blockIdx.x; gby = blockIdx.y; }
   const GjStep st = steps[(size_t)step * ndom + dz];
   const int n = st.n0;
-  if (kb >= st.nb || (int)blockIdx.x * GJ_T >= n || (int)blockIdx.y * GJ_T >= n) return;   // (the swap below stays inside the grid: td * GJ_T < n)
+  if (kb >= st.nb || gbx * GJ_T >= n || gby * GJ_T >= n) return;   // (the swap below stays inside the grid: td * GJ_T < n)
+  if (HEAD && (int)blockIdx.x >= ndom && gbx == kb && gby == kb) return;   // the pivot tile is one of the first ndom workgroups
   const GjDom dm = doms[dz];
   const int k0 = kb * GJ_B, bs = min(GJ_B, n - k0);
   const double *A = gj_src(dm, kb);
@@ -467,14 +487,14 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   // Look-ahead: the tile that holds the NEXT pivot block (diagonal tile td) also inverts it once it has updated it, so that
   // the next block step needs no pivot launch of its own (16 us of a serial 32-step chain per step, 5 400 steps per
   // realization at config 3). That tile is dealt first (swapped with tile (0, 0)) so that its longer life stays inside the launch.
-  const int k1 = k0 + GJ_B, td = k1 / GJ_T;
-  const bool ahead = kb + 1 < st.nb;
-  int bx = blockIdx.x, by = blockIdx.y;
-  if (ahead) {
+  const int k1 = k0 + GJ_B, td = HEAD ? kb : k1 / GJ_T;
+  const bool ahead = HEAD || kb + 1 < st.nb;
+  int bx = gbx, by = gby;
+  if (ahead && !HEAD) {
     if (bx == 0 && by == 0) bx = by = td;
     else if (bx == td && by == td) bx = by = 0;
   }
-  const bool special = ahead && bx == td && by == td;
+  const bool special = HEAD ? (int)blockIdx.x < ndom : (ahead && bx == td && by == td);
   // SYMMETRY. With σ(i) = -1 for the indices already swept (i < k0) and +1 otherwise, the matrix between two block steps
   // satisfies M[j,i] = σ(i) σ(j) M[i,j] (the inverse pivot block and the trailing part are symmetric, the row panel P A_Kj
   // and the column panel -A_iK P are each other's negative transpose; induction over the steps, P symmetric). Only the
@@ -482,9 +502,6 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   // LDS so that both stores are 128-byte segments). Storage stays full: the pick kernels and the next step's panel loads
   // read any entry.
   if (bx > by) return;
-#if defined(MI355_GJ_DIAG) && MI355_GJ_DIAG == 2
-  if (!special) return;   // timing experiment: only the chain (look-ahead tile + inversion) runs
-#endif
   const int i0 = bx * GJ_T, j0 = by * GJ_T;
 #ifdef MI355_GJ_STAMPS
   const bool dbg = step == 120 && kb == 2 && threadIdx.x == 0 && (special || ((bx * 7 + by * 3 + dz) % 29) == 0);
@@ -493,10 +510,6 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
 #define GJ_KSTAMP(i) do { if (dbg) ts[i] = wall_clock64(); } while (0)
 #else
 #define GJ_KSTAMP(i)
-#endif
-#if MI355_GJ_BULK_DELAY > 0
-  // experiment: the other tiles let the look-ahead tile's loads go first (off: it made every launch longer)
-  if (ahead && !special) for (int q = 0; q < MI355_GJ_BULK_DELAY; ++q) __builtin_amdgcn_s_sleep(127);
 #endif
   // LDS: A[K, J] / R (GJ_B x 65) and A[I, K] (64 x (GJ_B + 1)): 33.4 KB with a 32-wide pivot block (three workgroups per CU),
   // 66.6 KB with a 64-wide one (two). The pivot inverse P is NOT staged: every lane keeps the GJ_B / 4 entries it feeds to
@@ -519,8 +532,36 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   (void)TBW;
   const int tb = GJ_B == 64 ? wv : (wv & 1), jb0 = GJ_B == 64 ? 0 : 2 * (wv >> 1);
   double pa[GJ_B / 4];                                                   // P[16 tb + lc][kk + lk], kk = 0, 4, ...
+  if (HEAD && special) {
+    // the pivot block of this step: load, invert, publish (write-through stores, acknowledged, then the flag), and store
+    // this tile of the result — the inverse itself
+    for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) {
+      const int r = e % GJ_B, c = e / GJ_B;
+      R[r][c] = (r < bs && c < bs) ? A[(k0 + r) + (size_t)(k0 + c) * n] : (r == c ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    GJ_KSTAMP(1);
+    gj_invert_block(&R[0][0], GJ_T + 1, lds + LDS_R, lds + LDS_R + (GJ_B == 32 ? 0 : GJ_H * (GJ_T + 1)));
+    GJ_KSTAMP(2);
+    double *Pw = dm.P + (kb & 1) * (GJ_B * GJ_B);
+    for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) __hip_atomic_store(&Pw[e], R[e % GJ_B][e / GJ_B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(gj_ready_flag(dm), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    GJ_KSTAMP(3);
+#ifdef MI355_GJ_STAMPS
+    if (dbg) printf("PIVOT tile %2d %2d dom %d: start %lld loaded +%lld inverted +%lld published +%lld (n = %d)\n", bx, by, dz, ts[0], ts[1] - ts[0], ts[2] - ts[0], ts[3] - ts[0], n);
+#endif
+    for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) {
+      const int r = e % GJ_B, c = e / GJ_B;
+      if (r < bs && c < bs) O[(k0 + r) + (size_t)(k0 + c) * n] = R[r][c];
+    }
+    return;
+  }
+  if (!HEAD) {
 #pragma unroll
-  for (int q = 0; q < GJ_B / 4; ++q) pa[q] = Pcur[(16 * tb + lc) + (size_t)(4 * q + lk) * GJ_B];
+    for (int q = 0; q < GJ_B / 4; ++q) pa[q] = Pcur[(16 * tb + lc) + (size_t)(4 * q + lk) * GJ_B];
+  }
   for (int e = threadIdx.x; e < GJ_B * GJ_T; e += 256) {
     const int t = e % GJ_B, c = e / GJ_B;        // A[k0 + t, j0 + c]: consecutive threads walk down a column
     Ak[t][c] = (t < bs && j0 + c < n) ? A[(k0 + t) + (size_t)(j0 + c) * n] : 0.0;
@@ -548,6 +589,25 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
   // entries -(A_iK P): the SAME matrix-core loop as the trailing update with P in place of R and a zero start
   // (D[j][i] = Σ_u P[u][j] (-A[i][k0 + u])); the diagonal tile (kb, kb) becomes P itself.
   const bool kcol = GJ_B == GJ_T && by == kb;
+  GJ_KSTAMP(4);   // operand loads issued
+  if (HEAD) {
+    // P of this step: wait for the pivot tile's flag (bounded: a tile that gives up poisons its results, the finite check
+    // of the run then fails), then fetch it past the caches it was written through
+    __shared__ int gave_up;
+    if (threadIdx.x == 0) {
+      const unsigned *fl = gj_ready_flag(dm);
+      long long spins = 0;
+      while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq && spins < (1ll << 22)) { __builtin_amdgcn_s_sleep(32); ++spins; }
+      gave_up = spins >= (1ll << 22);
+    }
+    __syncthreads();
+    // Plain loads: no L2 holds a line of this P yet — the launch began with the caches' acquire, nobody has read P since
+    // (every reader waits for the flag), and the pivot tile wrote it through to memory before the flag. (Loads that bypass
+    // the L2 instead — 600 tiles x 32 KB from the same few channels — made a launch 20 us longer.)
+    const double poison = gave_up ? __builtin_nan("") : 0.0;
+#pragma unroll
+    for (int q = 0; q < GJ_B / 4; ++q) pa[q] = Pcur[(16 * tb + lc) + (size_t)(4 * q + lk) * GJ_B] + poison;
+  }
   __syncthreads();
   GJ_KSTAMP(1);   // operands loaded
   if (!kcol) {
@@ -569,7 +629,8 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
     }
   } else {
     __syncthreads();
-    for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256) R[e % GJ_B][e / GJ_B] = Pcur[e];   // P[u][jl] (columns beyond bs: identity, times a zero panel)
+    for (int e = threadIdx.x; e < GJ_B * GJ_B; e += 256)    // P[u][jl] (columns beyond bs: identity, times a zero panel)
+      R[e % GJ_B][e / GJ_B] = Pcur[e];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) acc[jt] = gj_d4{0.0, 0.0, 0.0, 0.0};
   }
@@ -603,7 +664,7 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
     }
   GJ_KSTAMP(2);   // tile updated and stored
 #ifdef MI355_GJ_STAMPS
-  if (dbg && !special) printf("tile %2d %2d dom %d: start %lld loaded +%lld updated +%lld\n", bx, by, dz, ts[0], ts[1] - ts[0], ts[2] - ts[0]);
+  if (dbg && !special) printf("tile %2d %2d dom %d: start %lld loaded +%lld updated +%lld (loads issued +%lld)\n", bx, by, dz, ts[0], ts[1] - ts[0], ts[2] - ts[0], ts[4] - ts[0]);
 #endif
   if (bx != by) {                                // the mirror image: M[j,i] = σ'(i) σ'(j) M[i,j], σ' = -1 below k1 (swept after this step)
     __syncthreads();                             // R, Cc are read for the last time above
@@ -627,10 +688,7 @@ __global__ __launch_bounds__(256) void k_gj_update(int step, int kb, int ndom, c
       }
     return;
   }
-  if (!special) return;
-#if defined(MI355_GJ_DIAG) && MI355_GJ_DIAG == 1
-  return;      // timing experiment: no look-ahead inversion (results are wrong)
-#endif
+  if (HEAD || !special) return;
   // Look-ahead: this diagonal tile holds the next pivot block (rows / columns k1 .. k1 + bs1 of the updated matrix); its inverse
   // goes to the other half of P. R becomes the landing zone (row stride GJ_T + 1), Cc the scratch of the block inversion.
   __syncthreads();
@@ -811,7 +869,7 @@ inline void gj_build(mi_setup_s &P) {
     const size_t nm = (size_t)std::max(1, D.max_lev), nt = (size_t)std::max<int>(std::max(1, D.max_lev), D.n_g);
     auto take = [&](size_t cnt) { const size_t o = tot; tot += (cnt + 31) / 32 * 32; return o; };
     off_T[d] = take(nt * nt); off_Z0[d] = take(nm * nm); off_Z1[d] = take(nm * nm);
-    off_y[d] = take(nm); off_g0[d] = take(nm); off_g1[d] = take(nm); off_P[d] = take(2 * GJ_B * GJ_B);
+    off_y[d] = take(nm); off_g0[d] = take(nm); off_g1[d] = take(nm); off_P[d] = take(2 * GJ_B * GJ_B + 16);   // (+ the step's ready flag)
   }
   G->pool.alloc(tot + 32);
   memset_sync(G->pool.p, 0, sizeof(double) * (tot + 32));
@@ -858,6 +916,10 @@ inline void gj_enqueue(mi_setup_s &P, hipStream_t s, const double *ii, const dou
   const GjDom *dm = G.doms.p;
   auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
   int nm = std::max(1, G.nmax);
+  constexpr bool gj_head = MI355_GJ_HEAD && GJ_B == GJ_T;
+  unsigned seq = 0;
+  if (nd > 1024) raise(MI_ERR_BAD_ARG, "device set-up: more than 1024 subdomains in one plan");
+  hipLaunchKernelGGL(k_gj_reset, dim3(1), dim3(1024), 0, s, nd, dm);
   for (int step = 0; step < G.nsteps; ++step) {
     nm = G.n_step[step];   // grids cover the largest level of this step only
     if (bI && step > 0) hipLaunchKernelGGL(k_gj_zg, dim3(cdiv(nm, 64), 1, nd), dim3(256), 0, s, step, nd, st, dm);
@@ -865,8 +927,10 @@ inline void gj_enqueue(mi_setup_s &P, hipStream_t s, const double *ii, const dou
     hipLaunchKernelGGL(k_gj_scatter, dim3(8, 1, nd), dim3(256), 0, s, step, nd, st, dm, P.src.p, P.dst.p, ii);
     if (bI) hipLaunchKernelGGL(k_gj_g, dim3(cdiv(nm, 256), 1, nd), dim3(256), 0, s, step, nd, st, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ii, P.perm.p, bI);
     for (int kb = 0; kb < G.nb_step[step]; ++kb) {
-      if (kb == 0) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nd), dim3(256), 0, s, step, kb, nd, st, dm);   // later pivots: look-ahead in the update
-      hipLaunchKernelGGL(k_gj_update, dim3(cdiv(nm, GJ_T), cdiv(nm, GJ_T), nd), dim3(256), 0, s, step, kb, nd, st, dm);
+      if (kb == 0 && !gj_head) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nd), dim3(256), 0, s, step, kb, nd, st, dm);   // later pivots: look-ahead in the update
+      const int tx = cdiv(nm, GJ_T);
+      if (gj_head) hipLaunchKernelGGL(k_gj_update, dim3(nd + tx * tx * nd), dim3(256), 0, s, step, kb, nd, st, dm, ++seq, tx);
+      else hipLaunchKernelGGL(k_gj_update, dim3(tx, tx, nd), dim3(256), 0, s, step, kb, nd, st, dm, ++seq, tx);
     }
     if (G.keep) hipLaunchKernelGGL(k_gj_keep, dim3(std::min(1024, cdiv(nm * nm, 1024)), 1, nd), dim3(256), 0, s, step, nd, st, dm, G.zstore.p);
   }
@@ -1061,7 +1125,7 @@ inline void pinv_blocks_fast(mi_ctx_s *c, int ndom, const int64_t *n_gamma_d, co
     const size_t n = (size_t)n_gamma_d[d], nn = std::max<size_t>(1, n * n);
     off[d] = run; run += n * n;
     auto take = [&](size_t cnt) { const size_t o = tot; tot += (cnt + 31) / 32 * 32; return o; };
-    oT[d] = take(nn); o0[d] = take(nn); o1[d] = take(nn); oP[d] = take(2 * GJ_B * GJ_B);
+    oT[d] = take(nn); o0[d] = take(nn); o1[d] = take(nn); oP[d] = take(2 * GJ_B * GJ_B + 16);
   }
   DevBuf<double> pool(tot + 32), norms((size_t)3 * ndom * 8);
   for (int d = 0; d < ndom; ++d) {
@@ -1085,9 +1149,14 @@ inline void pinv_blocks_fast(mi_ctx_s *c, int ndom, const int64_t *n_gamma_d, co
     }
     std_.upload(sb, s); dmd.upload(db, s);
     const int nb_ = (int)ds.size();
+    constexpr bool gj_head = MI355_GJ_HEAD && GJ_B == GJ_T;
+    if (nb_ > 1024) raise(MI_ERR_BAD_ARG, "pinv: more than 1024 blocks in one batch");
+    hipLaunchKernelGGL(k_gj_reset, dim3(1), dim3(1024), 0, s, nb_, dmd.p);
     for (int kb = 0; kb < nbmax; ++kb) {
-      if (kb == 0) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nb_), dim3(256), 0, s, 0, kb, nb_, std_.p, dmd.p);   // later pivots: look-ahead in the update
-      hipLaunchKernelGGL(k_gj_update, dim3(cdiv(nmax, GJ_T), cdiv(nmax, GJ_T), nb_), dim3(256), 0, s, 0, kb, nb_, std_.p, dmd.p);
+      if (kb == 0 && !gj_head) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nb_), dim3(256), 0, s, 0, kb, nb_, std_.p, dmd.p);   // later pivots: look-ahead in the update
+      const int tx = cdiv(nmax, GJ_T);
+      if (gj_head) hipLaunchKernelGGL(k_gj_update, dim3(nb_ + tx * tx * nb_), dim3(256), 0, s, 0, kb, nb_, std_.p, dmd.p, (unsigned)(kb + 1), tx);
+      else hipLaunchKernelGGL(k_gj_update, dim3(tx, tx, nb_), dim3(256), 0, s, 0, kb, nb_, std_.p, dmd.p, (unsigned)(kb + 1), tx);
     }
     for (size_t k = 0; k < ds.size(); ++k) {
       const int d = ds[k], n = (int)n_gamma_d[d];

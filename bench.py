@@ -629,6 +629,7 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             peer_on = bool(flag.item())
             if peer_on:
+                os.environ.setdefault("MI355_PEER_TIMEOUT_MS", "20000")     # (the self-check below must not sit out the library's 60 s)
                 ctx.peer_ready()
                 # a launch that waits for its peers' flags keeps its compute units: only when no two ranks share a GPU
                 ident = (os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
@@ -678,6 +679,34 @@ def main():
         ctx.synchronize()
         if multi:
             dist.barrier()
+
+    # ---------------- the peer exchange is checked on THIS machine before anything is timed: one solve through it against the
+    # same solve through RCCL's all-reduces (it was developed without a multi-GPU box). A rank that fails or
+    # disagrees sends every rank back to RCCL — a wrong or hanging exchange must never reach the timed region.
+    if multi and peer_on:
+        ok = 1
+        x_peer = torch.zeros(n_Γ, dtype=torch.float64, device="cuda")
+        x_rccl = torch.zeros(n_Γ, dtype=torch.float64, device="cuda")
+        it_p = -1
+        try:
+            _, it_p, _ = api.pcg(S, b_dev, x_peer, M, eps=args.eps)
+        except Exception as e:                                   # noqa: BLE001  (MI_ERR_COMM: a wait expired)
+            ok = 0
+            log(rank, f"peer exchange failed on rank {rank}: {e}")
+        ctx.set_exchange(0)
+        _, it_r, _ = api.pcg(S, b_dev, x_rccl, M, eps=args.eps)
+        if ok:
+            dx = float((x_peer - x_rccl).abs().max()) / max(float(x_rccl.abs().max()), 1e-300)
+            ok = int(it_p == it_r and dx <= 1e-9)
+            if not ok:
+                log(rank, f"peer exchange disagrees with RCCL on rank {rank}: it {it_p} vs {it_r}, |dx|/|x| = {dx:.2e}")
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()):
+            ctx.set_exchange(2 if peer_inwait else 1)
+        else:
+            peer_on = peer_inwait = False
+            log(rank, "peer exchange rejected by its self-check: RCCL all-reduces carry the Γ-sums of this run")
 
     # ---------------- warm-up, then the timed region: EXACTLY K solves
     its = None

@@ -339,11 +339,12 @@ struct DenseBlockOp : Operator {
   size_t fold_p1_off = 0;         // sharded Neumann-Neumann blocks: the second partial array (r'z) sits in the pack too
   // Peer exchange (exchange.hpp): the reduced pack is a double-buffered table at offset xt_off of every rank's arena;
   // own_idx lists the pack entries this rank's launches produce (contribution slots and per-row partials of its rows).
-  bool xt_on = false;
+  bool xt_built = false;           // this operator has a table in the arenas
+  bool xt_on() const { return xt_built && ctx->use_peer(); }   // ... and the exchange is switched on (mi_ctx_set_exchange)
   size_t xt_off = 0, xt_copy = 0;
   DevBuf<int> own_idx;
   int n_own = 0;
-  double *fold_reduced() const { return xt_on ? ctx->peer->local(xt_off) : fold_pack_all.p; }   // (peer: copy 0; the launches add the parity)
+  double *fold_reduced() const { return xt_on() ? ctx->peer->local(xt_off) : fold_pack_all.p; }   // (peer: copy 0; the launches add the parity)
   double *fold_con(bool reduced = false) const { return (reduced ? fold_reduced() : fold_pack.p); }
   double *fold_part0(bool reduced = false) const { return (reduced ? fold_reduced() : fold_pack.p) + fold_con_n; }
   double *fold_part1p(bool reduced = false) const { return fold_p1_off ? (reduced ? fold_reduced() : fold_pack.p) + fold_p1_off : fold_part1.p; }
@@ -352,13 +353,13 @@ struct DenseBlockOp : Operator {
   bool xt_direct = false;
   int n_active = 0;               // streamed tiles (the ones that count themselves in)
   void reduce_fold(const int *done, bool inwait) {
-    if (xt_on && xt_direct && inwait) return;    // the consuming launch waits itself
-    if (xt_on && xt_direct) ctx->peer->wait_advance(ctx->stream, done);
-    else if (xt_on) ctx->peer->push(xt_off, xt_copy, fold_pack.p, own_idx.p, n_own, ctx->stream, done);
+    if (xt_on() && xt_direct && inwait) return;    // the consuming launch waits itself
+    if (xt_on() && xt_direct) ctx->peer->wait_advance(ctx->stream, done);
+    else if (xt_on()) ctx->peer->push(xt_off, xt_copy, fold_pack.p, own_idx.p, n_own, ctx->stream, done);
     else ctx->allreduce(fold_pack.p, fold_pack_all.p, fold_pack_n);
   }
   void fold_outputs(PcgFold &f) const {   // con_out / part_out0 / part_out1 (+ the peer-store fields) of this operator's launch
-    if (xt_on && xt_direct) {
+    if (xt_on() && xt_direct) {
       double *t0 = ctx->peer->local(xt_off);
       f.con_out = t0; f.part_out0 = t0 + fold_con_n; f.part_out1 = fold_p1_off ? t0 + fold_p1_off : nullptr;
       f.xp = ctx->peer->peers_dev; f.xst = ctx->peer->st; f.out_stride = (long long)xt_copy; f.n_arrive = (unsigned int)n_active;
@@ -505,7 +506,7 @@ struct DenseBlockOp : Operator {
         own_idx.upload(own, c->stream);
         xt_copy = (fold_pack_n + 31) & ~(size_t)31;
         xt_off = c->peer->alloc(2 * xt_copy * sizeof(double));   // (zero since the arena was created: a bump allocator never re-uses)
-        xt_on = true;
+        xt_built = true;
         for (const GemvTile &t : tv) n_active += t.active != 0;
         xt_direct = n_active > 0 && !env_int("MI355_XCHG_PUSH_KERNEL", 0);   // (a rank without a block has nothing to count in: push kernel)
       }

@@ -330,7 +330,7 @@ struct Krylov {
   // peer exchange with the waits inside the launches: every sharded operator of the loop stores into the arenas itself
   bool inwait() const {
     return fold && ctx->peer_inwait && ctx->use_peer() && (Ad->reduce_over_ranks || Md->reduce_over_ranks) &&
-           (!Ad->reduce_over_ranks || (Ad->xt_on && Ad->xt_direct)) && (!Md->reduce_over_ranks || (Md->xt_on && Md->xt_direct));
+           (!Ad->reduce_over_ranks || (Ad->xt_on() && Ad->xt_direct)) && (!Md->reduce_over_ranks || (Md->xt_on() && Md->xt_direct));
   }
   PcgFold fold_args(int phase) const {
     PcgFold f{};
@@ -351,12 +351,12 @@ struct Krylov {
       f.con_in = Ad->fold_con(redA);
       f.part_in0 = Ad->fold_part0(redA); f.part_in1 = nullptr;
       Md->fold_outputs(f);
-      if (redA && Ad->xt_on) { f.in_epoch = &ctx->peer->st->epoch; f.in_stride = (long long)Ad->xt_copy; }
+      if (redA && Ad->xt_on()) { f.in_epoch = &ctx->peer->st->epoch; f.in_stride = (long long)Ad->xt_copy; }
     } else {      // S launch: reads ΠS contributions + partial r'r, r'z, writes S contributions + partial p'Ap
       f.con_in = Md->fold_con(redM);
       f.part_in0 = Md->fold_part0(redM); f.part_in1 = Md->fold_part1p(redM);
       Ad->fold_outputs(f);
-      if (redM && Md->xt_on) { f.in_epoch = &ctx->peer->st->epoch; f.in_stride = (long long)Md->xt_copy; }
+      if (redM && Md->xt_on()) { f.in_epoch = &ctx->peer->st->epoch; f.in_stride = (long long)Md->xt_copy; }
     }
     if (inwait()) { f.x_inwait = 1; f.xst = ctx->peer->st; f.xpw = ctx->peer->peers_dev; }
     return f;

@@ -655,7 +655,7 @@ def main():
     S = api.LocalSchurs(ctx, P.Sd, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(lo, hi))
     if not args.shard_precond:
         os.environ.pop("MI355_FORCE_REDUCE", None)        # (kept for the Neumann-Neumann blocks when they are "sharded" too)
-    if multi and not args.shard_precond:
+    def replicated_nn():
         # S is sharded (subdomain d on GPU d, one all-reduce per S-apply). The Neumann-Neumann blocks are replicated
         # on every rank instead (68 MB): the NN-apply is then purely local and an iteration needs ONE all-reduce.
         Pi_all = list(P.ΠSd)
@@ -666,7 +666,10 @@ def main():
                 torch.empty((nd, nd), dtype=torch.float64, device="cuda")
             dist.broadcast(t, owner)
             Pi_all[d] = np.asfortranarray(t.cpu().numpy()) if rank != owner else Pi_all[d]
-        M = api.NeumannNeumannSchurPreconditioner(ctx, Pi_all, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(0, ndom))
+        return api.NeumannNeumannSchurPreconditioner(ctx, Pi_all, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(0, ndom))
+
+    if multi and not args.shard_precond:
+        M = replicated_nn()
     else:
         M = api.NeumannNeumannSchurPreconditioner(ctx, P.ΠSd, P.sub.gather_idx, P.sub.node_Γ_cnt, dom_slice=(lo, hi))
     os.environ.pop("MI355_FORCE_REDUCE", None)
@@ -707,6 +710,38 @@ def main():
         else:
             peer_on = peer_inwait = False
             log(rank, "peer exchange rejected by its self-check: RCCL all-reduces carry the Γ-sums of this run")
+
+    # ---------------- `--exchange auto`: which of the two multi-GPU layouts is faster HERE — both operators sharded over the
+    # peer exchange, or S sharded + Neumann-Neumann blocks replicated with one RCCL all-reduce per iteration — is measured
+    # (3 solves each, maximum over the ranks), not assumed: the peer exchange has never met real xGMI.
+    layout_times = None
+    if multi and peer_on and args.exchange == "auto":
+        try:
+            M_rep = replicated_nn()
+            xq = torch.zeros(n_Γ, dtype=torch.float64, device="cuda")
+
+            def timed(Mx, mode):
+                ctx.set_exchange(mode)
+                xq.zero_(); api.pcg(S, b_dev, xq, Mx, eps=args.eps)           # graphs of this layout
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    xq.zero_(); api.pcg(S, b_dev, xq, Mx, eps=args.eps)
+                barrier()
+                return time.perf_counter() - t0
+            tt = torch.tensor([timed(M, 2 if peer_inwait else 1), timed(M_rep, 0)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            layout_times = {"peer_both_sharded_ms_per_solve": round(float(tt[0]) / 3 * 1e3, 4), "rccl_nn_replicated_ms_per_solve": round(float(tt[1]) / 3 * 1e3, 4)}
+            if float(tt[1]) < 0.97 * float(tt[0]):
+                M, peer_on, peer_inwait, args.shard_precond = M_rep, False, False, False
+                ctx.set_exchange(0)
+                log(rank, f"layout: RCCL with replicated Neumann-Neumann blocks is faster here {layout_times}")
+            else:
+                ctx.set_exchange(2 if peer_inwait else 1)
+                log(rank, f"layout: both operators sharded over the peer exchange {layout_times}")
+        except Exception as e:                                       # noqa: BLE001
+            ctx.set_exchange(2 if peer_inwait else 1)
+            log(rank, f"layout comparison skipped: {e}")
 
     # ---------------- warm-up, then the timed region: EXACTLY K solves
     its = None
@@ -756,7 +791,7 @@ def main():
         return float(np.median(ts))
 
     short = max(2, min(5, its - 2))
-    folded = (not multi or not args.shard_precond or peer_on) and its > short + 2   # sharded S (and, with the peer exchange, sharded NN blocks) also run the folded loop
+    folded = its > short + 2   # every layout runs the folded loop (sharded launches are followed by an exchange: peer stores or an RCCL all-reduce of the launch's table)
     k_us = None
     if folded:
         t_short = gpu_ms(short)
@@ -845,10 +880,11 @@ def main():
                                        + ("sharded: folded loop, two peer exchanges per iteration (the launches store into every rank's arena over xGMI and signal; "
                                           + ("the next launch waits for the flags itself" if peer_inwait else "a one-wave kernel waits for the flags") + ", csrc/exchange.hpp)"
                                           if args.shard_precond and peer_on else
-                                          "sharded: 4-launch loop, 2 RCCL all-reduces of the slot tables per iteration" if args.shard_precond
+                                          "sharded: folded loop, an RCCL all-reduce of the launch's table behind each of the two launches" if args.shard_precond
                                           else "replicated: folded loop, 1 exchange of the S launch's contribution table per iteration ("
                                                + ("peer stores" if peer_on else "RCCL all-reduce") + ")")),
                        "exchange": (("peer-inlaunch" if peer_inwait else "peer") if peer_on else "rccl") if multi else None,
+                       "layouts_measured": layout_times,
                        "it": its, "loop_iterations_per_solve": loop_its,
                        "final_relres": relres, "launches_per_iteration": 2 if folded else 4},
             "roofline": roofline,

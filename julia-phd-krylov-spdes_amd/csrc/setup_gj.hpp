@@ -459,13 +459,14 @@ __device__ __forceinline__ unsigned *gj_ready_flag(const GjDom &dm) { return rei
 __global__ void k_gj_reset(int ndom, const GjDom *__restrict__ doms) {
   if ((int)threadIdx.x < ndom) *gj_ready_flag(doms[threadIdx.x]) = 0u;
 }
+template <bool HEAD_T>
 __global__ __launch_bounds__(256, 3) void k_gj_update(int step, int kb, int ndom, const GjStep *__restrict__ steps,
                                                    const GjDom *__restrict__ doms, unsigned seq, int tiles_x) {
   // HEAD (MI355_GJ_HEAD=1, measured and not the default): the pivot block of THIS step is inverted at the head of the launch
   // by its own workgroup while every other tile loads its operands (the bandwidth-bound 7-10 us of a launch); the others
   // then wait for a per-subdomain flag and fetch P; no separate first-pivot launch per level. Small levels gain (37 us per
   // launch against ~45), the large ones lose more: their waiting tiles keep compute units that the look-ahead form uses.
-  constexpr bool HEAD = MI355_GJ_HEAD && GJ_B == GJ_T;
+  constexpr bool HEAD = HEAD_T && GJ_B == GJ_T;
   // HEAD: a 1-D grid whose FIRST ndom workgroups are the pivot tiles of the subdomains — dispatched before any tile that
   // will wait for them, whatever the number of resident workgroups (with the pivot tile merely first in its subdomain's
   // slab, slabs beyond the resident set started their inversion only when earlier slabs had finished: 128 us launches).
@@ -916,7 +917,8 @@ inline void gj_enqueue(mi_setup_s &P, hipStream_t s, const double *ii, const dou
   const GjDom *dm = G.doms.p;
   auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
   int nm = std::max(1, G.nmax);
-  constexpr bool gj_head = MI355_GJ_HEAD && GJ_B == GJ_T;
+  // levels of at most `head_maxn` nodes invert the step's pivot block at the head of the launch, larger ones look ahead
+  static const int head_maxn = GJ_B == GJ_T ? env_int("MI355_GJ_HEAD_MAXN", MI355_GJ_HEAD ? (1 << 30) : 0) : 0;
   unsigned seq = 0;
   if (nd > 1024) raise(MI_ERR_BAD_ARG, "device set-up: more than 1024 subdomains in one plan");
   hipLaunchKernelGGL(k_gj_reset, dim3(1), dim3(1024), 0, s, nd, dm);
@@ -926,11 +928,12 @@ inline void gj_enqueue(mi_setup_s &P, hipStream_t s, const double *ii, const dou
     hipLaunchKernelGGL(k_gj_pick, dim3(cdiv(nm, 16), cdiv(nm, 16), nd), dim3(256), 0, s, step, nd, st, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ii);
     hipLaunchKernelGGL(k_gj_scatter, dim3(8, 1, nd), dim3(256), 0, s, step, nd, st, dm, P.src.p, P.dst.p, ii);
     if (bI) hipLaunchKernelGGL(k_gj_g, dim3(cdiv(nm, 256), 1, nd), dim3(256), 0, s, step, nd, st, dm, P.c_ptr.p, P.c_row.p, P.c_src.p, ii, P.perm.p, bI);
+    const bool gj_head = nm <= head_maxn;
     for (int kb = 0; kb < G.nb_step[step]; ++kb) {
       if (kb == 0 && !gj_head) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nd), dim3(256), 0, s, step, kb, nd, st, dm);   // later pivots: look-ahead in the update
       const int tx = cdiv(nm, GJ_T);
-      if (gj_head) hipLaunchKernelGGL(k_gj_update, dim3(nd + tx * tx * nd), dim3(256), 0, s, step, kb, nd, st, dm, ++seq, tx);
-      else hipLaunchKernelGGL(k_gj_update, dim3(tx, tx, nd), dim3(256), 0, s, step, kb, nd, st, dm, ++seq, tx);
+      if (gj_head) hipLaunchKernelGGL(k_gj_update<true>, dim3(nd + tx * tx * nd), dim3(256), 0, s, step, kb, nd, st, dm, ++seq, tx);
+      else hipLaunchKernelGGL(k_gj_update<false>, dim3(tx, tx, nd), dim3(256), 0, s, step, kb, nd, st, dm, ++seq, tx);
     }
     if (G.keep) hipLaunchKernelGGL(k_gj_keep, dim3(std::min(1024, cdiv(nm * nm, 1024)), 1, nd), dim3(256), 0, s, step, nd, st, dm, G.zstore.p);
   }
@@ -1149,14 +1152,13 @@ inline void pinv_blocks_fast(mi_ctx_s *c, int ndom, const int64_t *n_gamma_d, co
     }
     std_.upload(sb, s); dmd.upload(db, s);
     const int nb_ = (int)ds.size();
-    constexpr bool gj_head = MI355_GJ_HEAD && GJ_B == GJ_T;
+    constexpr bool gj_head = false;   // (pinv batches: look-ahead form)
     if (nb_ > 1024) raise(MI_ERR_BAD_ARG, "pinv: more than 1024 blocks in one batch");
     hipLaunchKernelGGL(k_gj_reset, dim3(1), dim3(1024), 0, s, nb_, dmd.p);
     for (int kb = 0; kb < nbmax; ++kb) {
       if (kb == 0 && !gj_head) hipLaunchKernelGGL(k_gj_pivot, dim3(1, 1, nb_), dim3(256), 0, s, 0, kb, nb_, std_.p, dmd.p);   // later pivots: look-ahead in the update
       const int tx = cdiv(nmax, GJ_T);
-      if (gj_head) hipLaunchKernelGGL(k_gj_update, dim3(nb_ + tx * tx * nb_), dim3(256), 0, s, 0, kb, nb_, std_.p, dmd.p, (unsigned)(kb + 1), tx);
-      else hipLaunchKernelGGL(k_gj_update, dim3(tx, tx, nb_), dim3(256), 0, s, 0, kb, nb_, std_.p, dmd.p, (unsigned)(kb + 1), tx);
+      hipLaunchKernelGGL(k_gj_update<false>, dim3(tx, tx, nb_), dim3(256), 0, s, 0, kb, nb_, std_.p, dmd.p, (unsigned)(kb + 1), tx);
     }
     for (size_t k = 0; k < ds.size(); ++k) {
       const int d = ds[k], n = (int)n_gamma_d[d];

@@ -6,12 +6,16 @@ the Neumann-Neumann blocks replicated (one exchange per iteration) or sharded to
 (`it` equal, histories to the bar of DESIGN §3) and rank against rank (bit-identical).
 What this cannot show: timing and ordering of the peer stores on real xGMI (every arena is local memory here)."""
 import os
+import subprocess
+import sys
 import threading
 
 import numpy as np
 import pytest
 
 from conftest import f_m1, lognormal_coeff, u0734
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from test_gpu_parity import assert_history, orc_ops
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
@@ -248,3 +252,26 @@ def test_peer_exchange_across_processes(pkg, orc, fem, tmp_path):
     n, b = P.sub.n_Γ, P.b_schur
     assert np.allclose(r0["y"], So * b, rtol=0, atol=1e-13 * np.abs(r0["y"]).max())
     assert_history((r0["x"], int(r0["it"]), r0["res"]), orc.pcg(So, b, np.zeros(n), Mo))
+
+
+def test_bench_rehearses_its_multi_gpu_path_on_one_gpu():
+    """`bench.py --force-dist`: the code `--gpus N` runs — rendezvous, peer hand-shake, the self-check of the exchange
+    against RCCL, the timing of both layouts, the JSON contract — with ONE rank on this GPU (N = 200: seconds)."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--N", "200", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-secondary", "--kernel-reps", "20"]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 0
+    cfg = d["config"]
+    assert cfg["exchange"] in ("peer", "rccl") and cfg["launches_per_iteration"] == 2
+    lm = cfg["layouts_measured"]                                   # both layouts ran and were timed; the faster one was benchmarked
+    assert lm and lm["peer_both_sharded_ms_per_solve"] > 0 and lm["rccl_nn_replicated_ms_per_solve"] > 0
+    assert (cfg["exchange"] == "rccl") == (lm["rccl_nn_replicated_ms_per_solve"] < 0.97 * lm["peer_both_sharded_ms_per_solve"])
+    assert "peer exchange rejected" not in r.stderr

@@ -176,9 +176,18 @@ struct PeerComm {
     hipIpcMemHandle_t h;
     std::memcpy(&h, handle64, sizeof h);
     void *p = nullptr;
-    MI_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
-    base[q] = (char *)p;
+    MI_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));   // (the flag enables peer access between the two devices as needed)
     ipc_opened.push_back(p);
+    // a mapping this device's kernels cannot reach would fault inside a launch — a refusal here lets the caller fall back
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) == hipSuccess && at.device >= 0 && at.device != device) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, device, at.device) == hipSuccess && !can)
+        raise(MI_ERR_COMM, "peer exchange: device %d cannot access the memory of device %d (rank %d)", device, at.device, q);
+    } else {
+      (void)hipGetLastError();
+    }
+    base[q] = (char *)p;
   }
   XchgPeers *peers_dev = nullptr;    // the same structure in device memory (the folded launches read it through a pointer)
   void set_timeout_ms(long long ms) { set_timeout_ticks(ms * 100000ll); }   // 100 MHz ticks
